@@ -1,0 +1,196 @@
+/*
+ * hvrt.h -- C ABI of libhvrt: MI355X (gfx950) voxel-grid build + primary-ray grid traversal.
+ *
+ * This is the drop-in boundary for ONE hot path of Archibajl/RayTracer.  The reference has no FFI
+ * of its own (it is a single C++ program), so each entry point cites the reference C++ interface
+ * it stands in for; paths are relative to the reference's RayTracer/ directory.  The C++ class
+ * HipVoxelRayTracer (raytracer_amd/host/HipVoxelRayTracer.hpp) implements the reference's
+ * IRayTracer (IRayTracer.h:17-44) on top of exactly these calls; INTEGRATION.md shows the
+ * reference-side patch.
+ *
+ * Conventions: every function returns HVRT_OK (0) or a negative hvrt_status and never throws;
+ * hvrt_last_error() gives the message of the last failure on that context (or, with ctx == NULL,
+ * of the last failed hvrt_create on this thread).  The caller owns all host buffers; the context
+ * owns device memory, its HIP stream and its events.  Signatures use plain pointers and sizes
+ * only -- no HIP, torch or C++ types -- so host code compiles without HIP headers.  "Device
+ * pointer" arguments are raw addresses in the context's GPU (void*).  A context is bound to one
+ * GPU and is not thread-safe; one process per GPU is the intended multi-GPU model.
+ *
+ * All results are defined by the reference's arithmetic (IEEE fp32, no FMA contraction, NaN/inf
+ * control flow included): the voxel CSR is bit-exact, hit ids / t / colours are bit-exact with the
+ * CPU restatement in oracle/ (tests/).
+ */
+#ifndef HVRT_H
+#define HVRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HVRT_MISS 0xFFFFFFFFu /* hit_id value for "no triangle" */
+
+typedef enum hvrt_status {
+    HVRT_OK = 0,
+    HVRT_ERR_INVALID = -1,   /* bad argument / call order (message says which) */
+    HVRT_ERR_NO_DEVICE = -2, /* no usable HIP device */
+    HVRT_ERR_HIP = -3,       /* a HIP runtime call failed (message carries hipGetErrorString) */
+    HVRT_ERR_OOM = -4,       /* device allocation failed */
+    HVRT_ERR_OVERFLOW = -5   /* more than 2^32-1 triangle references (CSR offsets are u32 as in Voxels.h:19-20) */
+} hvrt_status;
+
+typedef struct hvrt_ctx hvrt_ctx;
+
+/* Loop-invariant head of OctreeLikeRayTracer::generateRay (OctreeLikeRayTracer.cpp:342-359),
+ * computed once on the host (tan() is libm-dependent; everything per pixel is + - * / sqrt). */
+typedef struct hvrt_camera_frame {
+    float origin[3];
+    float lower_left[3];
+    float horizontal[3];
+    float vertical[3];
+} hvrt_camera_frame;
+
+/* Same fields and layout as cg_datastructures::RayHit (RayTracerCommon.h:17-29), 52 bytes;
+ * bool hit widened to 32 bits (the reference struct has 3 bytes of padding there). */
+typedef struct hvrt_hit {
+    uint32_t hit;
+    float t;          /* FLT_MAX on a miss */
+    float point[3];   /* = triangle.v0, as the reference sets it (OctreeLikeRayTracer.cpp:286) */
+    float origin[3];
+    float normal[3];  /* raw file normal of the hit triangle */
+    uint32_t triangle_index;
+    uint32_t voxel_index; /* always 0, as in the reference */
+} hvrt_hit;
+
+typedef struct hvrt_grid_info {
+    int32_t nx, ny, nz;
+    float min_bound[3];
+    float max_bound[3];
+    float voxel_size[3];
+    uint64_t n_voxels;
+    uint64_t n_refs;       /* length of the CSR index array */
+    uint64_t n_occupied;   /* voxels with count > 0 (VoxelizationResult::occupied_count) */
+    uint32_t max_list;     /* longest per-voxel list */
+    uint32_t n_triangles;
+} hvrt_grid_info;
+
+/* Per-call device timings (HIP events on the context's stream), milliseconds. */
+typedef struct hvrt_timings {
+    float build_total_ms;   /* hvrt_build_grid: count + scan + fill + order */
+    float build_count_ms;
+    float build_scan_ms;
+    float build_fill_ms;
+    float build_sort_ms;
+    float render_ms;        /* last hvrt_render* traversal kernel(s) */
+    float trace_ms;         /* last hvrt_trace */
+} hvrt_timings;
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Replaces: constructing a tracer (OctreeRayTracer.h:30).  device_id = HIP device ordinal. */
+int hvrt_create(hvrt_ctx** out, int device_id);
+void hvrt_destroy(hvrt_ctx* ctx);
+const char* hvrt_last_error(const hvrt_ctx* ctx);
+/* The context's HIP stream as an opaque handle (hipStream_t), for callers that interleave their
+ * own work (e.g. RCCL collectives) with hvrt calls. */
+void* hvrt_stream(hvrt_ctx* ctx);
+int hvrt_synchronize(hvrt_ctx* ctx);
+int hvrt_get_timings(const hvrt_ctx* ctx, hvrt_timings* out);
+
+/* ---- mesh ---------------------------------------------------------------------------------- */
+
+/* Replaces: buildTriangleList's output `std::vector<Triangle>` (SceneCreator.cpp:129-170,
+ * Voxels.h:10-13).  tri_aos = n_tris x 12 floats (v0, v1, v2, normal), host memory. */
+int hvrt_set_mesh(hvrt_ctx* ctx, const float* tri_aos, uint32_t n_tris);
+/* Same, from a device pointer in the same layout (used after an RCCL broadcast). */
+int hvrt_set_mesh_device(hvrt_ctx* ctx, const void* d_tri_aos, uint32_t n_tris);
+
+/* Replaces: computeMeshBounds (SceneCreator.cpp:49-84) on the GPU: fp32 min/max over n_points
+ * xyz triples (host memory) in the reference's sequential semantics (first occurrence wins ties,
+ * NaNs ignored).  The reference feeds it the de-duplicated STL vertex list. */
+int hvrt_compute_bounds(hvrt_ctx* ctx, const float* points_xyz, uint64_t n_points,
+                        float min_out[3], float max_out[3]);
+/* Same over the 3*n_tris corners of the resident mesh (device-resident input). */
+int hvrt_mesh_bounds(hvrt_ctx* ctx, float min_out[3], float max_out[3]);
+
+/* Replaces: computeVoxelizationParams (SceneCreator.cpp:91-122): the uniform voxel size
+ * max(extent) / (float)max(nx,ny,nz).  Pure host arithmetic. */
+float hvrt_voxel_size(const float min_bound[3], const float max_bound[3], int nx, int ny, int nz);
+
+/* ---- voxel grid ---------------------------------------------------------------------------- */
+
+/* Replaces: voxelizeTrianglesDirect + createVoxelGrid (SceneCreator.cpp:197-302), and the dead
+ * GPU/inline variants (SceneCreator.cu:67-358, InlineVoxelizer.h:17-167).  Builds the CSR
+ * voxel -> triangle-index structure of the resident mesh on the GPU: per-triangle AABB voxel
+ * range (SceneCreator.cpp:23-37,177-188), counts, exclusive scan in flat order
+ * ix + nx*(iy + ny*iz), scatter, per-voxel ascending order.  voxel_size is per axis (the reference
+ * builder passes the same value three times). */
+int hvrt_build_grid(hvrt_ctx* ctx, int nx, int ny, int nz,
+                    const float min_bound[3], const float max_bound[3], const float voxel_size[3]);
+
+/* Replaces: handing a CPU-built VoxelGrid to a tracer (OctreeRayTracer.h:30, VoxelGrid.h:8-42).
+ * offsets = n_voxels+1 exclusive-scan entries in flat order, indices = offsets[n_voxels] entries;
+ * host memory. */
+int hvrt_set_grid_csr(hvrt_ctx* ctx, int nx, int ny, int nz,
+                      const float min_bound[3], const float max_bound[3], const float voxel_size[3],
+                      const uint32_t* offsets, const uint32_t* indices);
+/* Same from device pointers (used after an RCCL broadcast of a grid built on another GPU). */
+int hvrt_set_grid_csr_device(hvrt_ctx* ctx, int nx, int ny, int nz,
+                             const float min_bound[3], const float max_bound[3], const float voxel_size[3],
+                             const void* d_offsets, const void* d_indices, uint64_t n_refs);
+
+int hvrt_get_grid_info(const hvrt_ctx* ctx, hvrt_grid_info* out);
+/* Replaces: reading VoxelGrid::voxels[x][y][z].{triangle_start_idx,triangle_count} and
+ * VoxelGrid::triangle_indices.  Copies the CSR to host memory; either pointer may be NULL. */
+int hvrt_get_csr(hvrt_ctx* ctx, uint32_t* offsets, uint32_t* indices);
+/* Device addresses of the resident arrays (for RCCL broadcast by the caller). */
+int hvrt_get_device_arrays(hvrt_ctx* ctx, void** d_tri_aos, void** d_offsets, void** d_indices);
+
+/* ---- rendering ----------------------------------------------------------------------------- */
+
+/* Replaces: the loop-invariant part of generateRay (OctreeLikeRayTracer.cpp:342-359).  Host. */
+void hvrt_make_camera_frame(const float position[3], const float look_at[3], const float up[3],
+                            float fov_degrees, float aspect, hvrt_camera_frame* out);
+
+/* Replaces: OctreeLikeRayTracer::render (OctreeLikeRayTracer.cpp:88-118).  Traces one primary ray
+ * per sample through pixel corners (u = x/W, v = y/H; row 0 = bottom of the view), shades
+ * (OctreeLikeRayTracer.cpp:27-40, Shaders.cpp:4-22) and returns host arrays indexed y*W + x:
+ *   rgb      W*H*3 floats                      (the reference's return value)
+ *   hit_id   W*H u32, HVRT_MISS on a miss      (nullable)
+ *   t        W*H floats, FLT_MAX on a miss     (nullable)
+ *   counters {voxels tested, ray/triangle tests} summed over all rays, counted once per ray
+ *            (the reference traces every ray twice, so it logs twice these) (nullable)
+ * spp == 1 reproduces the reference; spp > 1 adds counter-hash jitter in [0,1)^2 and averages
+ * (an extension; hit_id / t are those of sample 0). */
+int hvrt_render(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int width, int height,
+                int spp, uint32_t seed,
+                float* rgb, uint32_t* hit_id, float* t, uint64_t counters[2]);
+
+/* Device-resident form, and the multi-GPU partition: the image is cut into row tiles of tile_rows
+ * rows; tile k belongs to part (k % n_parts).  This call renders the tiles of `part` into compact
+ * device buffers holding hvrt_part_rows() rows of `width` pixels, in tile order.  n_parts == 1
+ * renders the whole frame.  Outputs are device pointers (each nullable): d_rgb 3 floats / px,
+ * d_hit_id u32 / px, d_t float / px, d_counters 2 x u64 (accumulated into: zero it first).
+ * Asynchronous on the context's stream. */
+int hvrt_render_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int width, int height,
+                            int spp, uint32_t seed, int tile_rows, int part, int n_parts,
+                            void* d_rgb, void* d_hit_id, void* d_t, void* d_counters);
+/* Rows owned by `part` (host arithmetic). */
+int hvrt_part_rows(int height, int tile_rows, int part, int n_parts);
+/* Reassembles a frame from gathered parts: d_parts holds n_parts slabs of slab_rows x width
+ * pixels of bytes_per_pixel bytes each (slab_rows >= hvrt_part_rows of every part); writes
+ * height x width pixels to d_frame.  Asynchronous on the context's stream. */
+int hvrt_assemble_parts_device(hvrt_ctx* ctx, const void* d_parts, int width, int height,
+                               int tile_rows, int n_parts, int slab_rows, int bytes_per_pixel,
+                               void* d_frame);
+
+/* Replaces: OctreeLikeRayTracer::traceRay (OctreeLikeRayTracer.cpp:124-126), batched.
+ * origins / dirs = n x 3 floats, out = n records; host memory. */
+int hvrt_trace(hvrt_ctx* ctx, const float* origins, const float* dirs, uint32_t n,
+               hvrt_hit* out, uint64_t counters[2]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HVRT_H */

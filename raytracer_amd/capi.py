@@ -1,0 +1,294 @@
+"""ctypes binding of libhvrt (include/hvrt.h) -- the Python-side mirror of the C ABI.
+
+Nothing here computes anything on the CPU: every method forwards to the HIP library and raises
+``HvrtError`` on a non-zero status.  If the shared library is missing the import of
+``raytracer_amd`` still works (so that CPU-only tooling can load), but creating a ``Context`` or
+calling any entry point raises loudly -- there is no fallback path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhvrt.so")
+
+HVRT_MISS = 0xFFFFFFFF
+
+# every symbol include/hvrt.h declares (tests check the library exports each of them)
+SYMBOLS = [
+    "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_synchronize", "hvrt_get_timings",
+    "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
+    "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
+    "hvrt_get_device_arrays", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device",
+    "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace",
+]
+
+
+class HvrtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"hvrt error {code}: {msg}")
+        self.code = code
+
+
+class CameraFrame(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left", C.c_float * 3),
+                ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3)]
+
+
+class GridInfo(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("min_bound", C.c_float * 3), ("max_bound", C.c_float * 3), ("voxel_size", C.c_float * 3),
+                ("n_voxels", C.c_uint64), ("n_refs", C.c_uint64), ("n_occupied", C.c_uint64),
+                ("max_list", C.c_uint32), ("n_triangles", C.c_uint32)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("build_total_ms", C.c_float), ("build_count_ms", C.c_float), ("build_scan_ms", C.c_float),
+                ("build_fill_ms", C.c_float), ("build_sort_ms", C.c_float), ("render_ms", C.c_float),
+                ("trace_ms", C.c_float)]
+
+
+HIT_DTYPE = np.dtype([("hit", "<u4"), ("t", "<f4"), ("point", "<f4", 3), ("origin", "<f4", 3),
+                      ("normal", "<f4", 3), ("triangle_index", "<u4"), ("voxel_index", "<u4")])
+assert HIT_DTYPE.itemsize == 52
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libhvrt.so (built in-tree by raytracer_amd/csrc/Makefile).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HvrtError(-100, f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                              "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    vp, f3 = C.c_void_p, C.POINTER(C.c_float)
+    lib.hvrt_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.hvrt_destroy.argtypes = [vp]
+    lib.hvrt_destroy.restype = None
+    lib.hvrt_last_error.argtypes = [vp]
+    lib.hvrt_last_error.restype = C.c_char_p
+    lib.hvrt_stream.argtypes = [vp]
+    lib.hvrt_stream.restype = vp
+    lib.hvrt_synchronize.argtypes = [vp]
+    lib.hvrt_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    lib.hvrt_set_mesh.argtypes = [vp, vp, C.c_uint32]
+    lib.hvrt_set_mesh_device.argtypes = [vp, vp, C.c_uint32]
+    lib.hvrt_compute_bounds.argtypes = [vp, vp, C.c_uint64, f3, f3]
+    lib.hvrt_mesh_bounds.argtypes = [vp, f3, f3]
+    lib.hvrt_voxel_size.argtypes = [f3, f3, C.c_int, C.c_int, C.c_int]
+    lib.hvrt_voxel_size.restype = C.c_float
+    lib.hvrt_build_grid.argtypes = [vp, C.c_int, C.c_int, C.c_int, f3, f3, f3]
+    lib.hvrt_set_grid_csr.argtypes = [vp, C.c_int, C.c_int, C.c_int, f3, f3, f3, vp, vp]
+    lib.hvrt_set_grid_csr_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, f3, f3, f3, vp, vp, C.c_uint64]
+    lib.hvrt_get_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
+    lib.hvrt_get_csr.argtypes = [vp, vp, vp]
+    lib.hvrt_get_device_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.hvrt_make_camera_frame.argtypes = [f3, f3, f3, C.c_float, C.c_float, C.POINTER(CameraFrame)]
+    lib.hvrt_make_camera_frame.restype = None
+    lib.hvrt_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp]
+    lib.hvrt_render_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                            C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.hvrt_part_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.hvrt_assemble_parts_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+    lib.hvrt_trace.argtypes = [vp, vp, vp, C.c_uint32, vp, vp]
+    _lib = lib
+    return lib
+
+
+def _f3(a) -> "C.Array":
+    a = np.asarray(a, dtype=np.float32).reshape(3)
+    return (C.c_float * 3)(*[float(x) for x in a])
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def make_camera_frame(position, look_at, up, fov_degrees: float, aspect: float) -> CameraFrame:
+    """Loop-invariant head of generateRay (OctreeLikeRayTracer.cpp:342-359), computed by libhvrt."""
+    lib = load_library()
+    fr = CameraFrame()
+    lib.hvrt_make_camera_frame(_f3(position), _f3(look_at), _f3(up), C.c_float(fov_degrees), C.c_float(aspect),
+                               C.byref(fr))
+    return fr
+
+
+def voxel_size(min_bound, max_bound, nx: int, ny: int, nz: int) -> np.float32:
+    lib = load_library()
+    return np.float32(lib.hvrt_voxel_size(_f3(min_bound), _f3(max_bound), nx, ny, nz))
+
+
+def part_rows(height: int, tile_rows: int, part: int, n_parts: int) -> int:
+    return load_library().hvrt_part_rows(height, tile_rows, part, n_parts)
+
+
+def default_camera(min_bound, max_bound, view: str = "front", aspect: float = 800.0 / 600.0):
+    """TraceImages::setupCamera / setupCameraWithView (TraceImages.cpp:125-197): position, lookAt, up,
+    fov 60, aspect (the reference hard-codes 800/600).  fp32 arithmetic as in the reference."""
+    mn = np.asarray(min_bound, np.float32)
+    mx = np.asarray(max_bound, np.float32)
+    center = ((mn + mx) * np.float32(0.5)).astype(np.float32)      # VoxelGrid.h:30-32
+    size = (mx - mn).astype(np.float32)
+    dist = np.float32(np.max(size)) * np.float32(2.5)
+    pos = center.copy()
+    up = np.array([0, 1, 0], np.float32)
+    if view == "front":
+        pos[2] = center[2] - dist
+    elif view == "side":
+        pos[0] = center[0] + dist
+    elif view == "top":
+        pos[1] = center[1] + dist
+        up = np.array([0, 0, 1], np.float32)
+    else:
+        raise ValueError(view)
+    return pos, center, up, 60.0, float(np.float32(aspect))
+
+
+@dataclass
+class BuildResult:
+    info: GridInfo
+    timings: Timings
+
+
+class Context:
+    """One GPU, one scene (mirrors the life cycle of the reference's tracer object)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        rc = self._lib.hvrt_create(C.byref(h), device_id)
+        if rc != 0:
+            raise HvrtError(rc, self._lib.hvrt_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.hvrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise HvrtError(rc, self._lib.hvrt_last_error(self._h).decode())
+
+    # -- mesh
+    def set_mesh(self, tri_aos: np.ndarray):
+        t = np.ascontiguousarray(tri_aos, dtype=np.float32).reshape(-1, 12)
+        self._ck(self._lib.hvrt_set_mesh(self._h, _ptr(t), t.shape[0]))
+
+    def set_mesh_device(self, d_ptr: int, n_tris: int):
+        self._ck(self._lib.hvrt_set_mesh_device(self._h, C.c_void_p(d_ptr), n_tris))
+
+    def compute_bounds(self, points: np.ndarray):
+        p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+        mn, mx = (C.c_float * 3)(), (C.c_float * 3)()
+        self._ck(self._lib.hvrt_compute_bounds(self._h, _ptr(p), p.shape[0], mn, mx))
+        return np.array(mn, np.float32), np.array(mx, np.float32)
+
+    def mesh_bounds(self):
+        mn, mx = (C.c_float * 3)(), (C.c_float * 3)()
+        self._ck(self._lib.hvrt_mesh_bounds(self._h, mn, mx))
+        return np.array(mn, np.float32), np.array(mx, np.float32)
+
+    # -- grid
+    def build_grid(self, nx, ny, nz, min_bound, max_bound, voxel_size3) -> GridInfo:
+        vs = np.broadcast_to(np.asarray(voxel_size3, np.float32), (3,))
+        self._ck(self._lib.hvrt_build_grid(self._h, nx, ny, nz, _f3(min_bound), _f3(max_bound), _f3(vs)))
+        return self.grid_info()
+
+    def set_grid_csr(self, nx, ny, nz, min_bound, max_bound, voxel_size3, offsets, indices):
+        vs = np.broadcast_to(np.asarray(voxel_size3, np.float32), (3,))
+        o = np.ascontiguousarray(offsets, dtype=np.uint32)
+        i = np.ascontiguousarray(indices, dtype=np.uint32)
+        if o.shape[0] != nx * ny * nz + 1:
+            raise ValueError("offsets must have nx*ny*nz+1 entries")
+        if i.shape[0] != int(o[-1]):
+            raise ValueError("indices must have offsets[-1] entries")
+        self._ck(self._lib.hvrt_set_grid_csr(self._h, nx, ny, nz, _f3(min_bound), _f3(max_bound), _f3(vs),
+                                             _ptr(o), _ptr(i) if i.size else None))
+
+    def set_grid_csr_device(self, nx, ny, nz, min_bound, max_bound, voxel_size3, d_offsets: int, d_indices: int,
+                            n_refs: int):
+        vs = np.broadcast_to(np.asarray(voxel_size3, np.float32), (3,))
+        self._ck(self._lib.hvrt_set_grid_csr_device(self._h, nx, ny, nz, _f3(min_bound), _f3(max_bound), _f3(vs),
+                                                    C.c_void_p(d_offsets), C.c_void_p(d_indices), n_refs))
+
+    def grid_info(self) -> GridInfo:
+        gi = GridInfo()
+        self._ck(self._lib.hvrt_get_grid_info(self._h, C.byref(gi)))
+        return gi
+
+    def get_csr(self):
+        gi = self.grid_info()
+        off = np.empty(gi.n_voxels + 1, np.uint32)
+        idx = np.empty(gi.n_refs, np.uint32)
+        self._ck(self._lib.hvrt_get_csr(self._h, _ptr(off), _ptr(idx) if idx.size else None))
+        return off, idx
+
+    def device_arrays(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._ck(self._lib.hvrt_get_device_arrays(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self._ck(self._lib.hvrt_get_timings(self._h, C.byref(t)))
+        return t
+
+    def synchronize(self):
+        self._ck(self._lib.hvrt_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return self._lib.hvrt_stream(self._h) or 0
+
+    # -- rendering
+    def render(self, frame: CameraFrame, width: int, height: int, spp: int = 1, seed: int = 0,
+               want_hit=True, want_t=True, want_counters=True):
+        rgb = np.empty((height, width, 3), np.float32)
+        hit = np.empty((height, width), np.uint32) if want_hit else None
+        t = np.empty((height, width), np.float32) if want_t else None
+        cnt = np.zeros(2, np.uint64) if want_counters else None
+        self._ck(self._lib.hvrt_render(self._h, C.byref(frame), width, height, spp, seed,
+                                       _ptr(rgb), _ptr(hit), _ptr(t), _ptr(cnt)))
+        return rgb, hit, t, cnt
+
+    def render_part_device(self, frame: CameraFrame, width: int, height: int, spp: int, seed: int,
+                           tile_rows: int, part: int, n_parts: int,
+                           d_rgb: int = 0, d_hit: int = 0, d_t: int = 0, d_counters: int = 0):
+        vp = lambda p: C.c_void_p(p) if p else None
+        self._ck(self._lib.hvrt_render_part_device(self._h, C.byref(frame), width, height, spp, seed, tile_rows,
+                                                   part, n_parts, vp(d_rgb), vp(d_hit), vp(d_t), vp(d_counters)))
+
+    def assemble_parts_device(self, d_parts: int, width: int, height: int, tile_rows: int, n_parts: int,
+                              slab_rows: int, bytes_per_pixel: int, d_frame: int):
+        self._ck(self._lib.hvrt_assemble_parts_device(self._h, C.c_void_p(d_parts), width, height, tile_rows,
+                                                      n_parts, slab_rows, bytes_per_pixel, C.c_void_p(d_frame)))
+
+    def trace(self, origins: np.ndarray, dirs: np.ndarray, want_counters=True):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
+        if o.shape != d.shape:
+            raise ValueError("origins and dirs must have the same shape")
+        out = np.zeros(o.shape[0], HIT_DTYPE)
+        cnt = np.zeros(2, np.uint64) if want_counters else None
+        self._ck(self._lib.hvrt_trace(self._h, _ptr(o), _ptr(d), o.shape[0], _ptr(out), _ptr(cnt)))
+        return out, cnt

@@ -1,0 +1,551 @@
+// hvrt_api.hip -- the C ABI of libhvrt (include/hvrt.h): context, device memory, kernel sequencing.
+// Host code only; the kernels live in hvrt_build.hip / hvrt_trace.hip.  No CPU fallback exists:
+// every entry point either runs on the GPU or returns an error.
+#include "hvrt_internal.hpp"
+
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace hvrt;
+
+struct hvrt_ctx {
+    int device = 0;
+    int n_cus = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    std::string error;
+
+    // mesh
+    float* tri_aos = nullptr;      // owned unless aos_external
+    float4* tri_rec = nullptr;
+    uint32_t n_tris = 0;
+    uint64_t aos_capacity = 0;     // floats
+    uint64_t rec_capacity = 0;     // float4s
+
+    // grid
+    bool has_grid = false;
+    GridParams g = {};
+    float max_bound[3] = {};
+    uint32_t* cnt_base = nullptr;  // offsets = cnt_base + 3
+    uint64_t cnt_capacity = 0;     // u32 elements
+    uint32_t* indices = nullptr;
+    uint64_t indices_capacity = 0;
+    uint64_t n_refs = 0, n_occupied = 0;
+    uint32_t max_list = 0;
+
+    // build scratch
+    uint32_t* ranges = nullptr;   uint64_t ranges_capacity = 0;
+    uint64_t* block_sums = nullptr; uint64_t block_sums_capacity = 0;
+    uint64_t* stats = nullptr;     // 8 x u64
+    uint32_t* long_queue = nullptr; uint64_t long_queue_capacity = 0;
+    float* bounds_v = nullptr; uint64_t* bounds_i = nullptr; float* bounds_out = nullptr;
+
+    // render scratch
+    uint32_t* tile_counter = nullptr;
+    unsigned long long* counters = nullptr;   // 2 x u64
+    void* out_buf[3] = {};  uint64_t out_cap[3] = {};   // rgb / hit / t staging for host-facing render
+    void* io_buf[3] = {};   uint64_t io_cap[3] = {};    // trace staging: origins / dirs / hits
+
+    hvrt_timings tm = {};
+    bool render_pending = false;   // ev[6..7] recorded by an asynchronous render, not yet read
+};
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(hvrt_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(c, call)                                                                               \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail((c), e_ == hipErrorOutOfMemory ? HVRT_ERR_OOM : HVRT_ERR_HIP, "%s failed: %s", \
+                        #call, hipGetErrorString(e_));                                                 \
+    } while (0)
+
+template <typename T>
+int ensure(hvrt_ctx* c, T*& p, uint64_t& cap, uint64_t need) {
+    if (need <= cap && p) return HVRT_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (need == 0) need = 1;
+    hipError_t e = hipMalloc((void**)&p, need * sizeof(T));
+    if (e != hipSuccess) { p = nullptr; return fail(c, HVRT_ERR_OOM, "hipMalloc of %llu bytes failed: %s",
+                                                    (unsigned long long)(need * sizeof(T)), hipGetErrorString(e)); }
+    cap = need;
+    return HVRT_OK;
+}
+int ensure_bytes(hvrt_ctx* c, void*& p, uint64_t& cap, uint64_t need) {
+    char* q = (char*)p;
+    int r = ensure<char>(c, q, cap, need);
+    p = q;
+    return r;
+}
+
+int bind(hvrt_ctx* c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return HVRT_OK;
+}
+
+uint32_t* offsets_of(const hvrt_ctx* c) { return c->cnt_base + 3; }
+uint32_t* cnt_of(const hvrt_ctx* c) { return c->cnt_base + 4; }   // 16-byte aligned
+
+uint64_t padded_vox(uint64_t nvox) { return (nvox + SCAN_CHUNK - 1) / SCAN_CHUNK * SCAN_CHUNK; }
+
+int check_grid_args(hvrt_ctx* c, int nx, int ny, int nz, const float* mn, const float* mx, const float* vs) {
+    if (!mn || !mx || !vs) return fail(c, HVRT_ERR_INVALID, "grid: null bounds / voxel size");
+    if (nx < 1 || ny < 1 || nz < 1) return fail(c, HVRT_ERR_INVALID, "grid: dimensions must be >= 1 (got %d x %d x %d)", nx, ny, nz);
+    if (nx > 65536 || ny > 65536 || nz > 65536) return fail(c, HVRT_ERR_INVALID, "grid: at most 65536 voxels per axis");
+    uint64_t nvox = (uint64_t)nx * ny * nz;
+    if (nvox > 0xFFFFFFFFull - 2 * SCAN_CHUNK) return fail(c, HVRT_ERR_INVALID, "grid: at most 2^32 - 8192 voxels");
+    return HVRT_OK;
+}
+
+void set_grid_params(hvrt_ctx* c, int nx, int ny, int nz, const float* mn, const float* mx, const float* vs) {
+    c->g.nx = nx; c->g.ny = ny; c->g.nz = nz;
+    c->g.mnx = mn[0]; c->g.mny = mn[1]; c->g.mnz = mn[2];
+    c->g.vsx = vs[0]; c->g.vsy = vs[1]; c->g.vsz = vs[2];
+    c->g.nvox = (uint64_t)nx * ny * nz;
+    memcpy(c->max_bound, mx, 12);
+}
+
+SceneDev scene_of(const hvrt_ctx* c) {
+    SceneDev s;
+    s.g = c->g;
+    s.tri_rec = c->tri_rec;
+    s.offsets = offsets_of(c);
+    s.indices = c->indices;
+    s.n_tris = c->n_tris;
+    return s;
+}
+
+int require_scene(hvrt_ctx* c) {
+    if (!c->n_tris && !c->tri_rec) return fail(c, HVRT_ERR_INVALID, "no mesh: call hvrt_set_mesh first");
+    if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "no grid: call hvrt_build_grid or hvrt_set_grid_csr first");
+    return HVRT_OK;
+}
+
+float ms_between(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hvrt_create(hvrt_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, HVRT_ERR_INVALID, "hvrt_create: out is null");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, HVRT_ERR_NO_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n)
+        return fail(nullptr, HVRT_ERR_INVALID, "device_id %d out of range (0..%d)", device_id, n - 1);
+    hvrt_ctx* c = new hvrt_ctx();
+    c->device = device_id;
+    auto bail = [&](const char* what, hipError_t err) {
+        fail(nullptr, HVRT_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
+        hvrt_destroy(c);
+        return HVRT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return bail("hipSetDevice", e);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (auto& ev : c->ev)
+        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc((void**)&c->stats, 8 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->tile_counter, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->bounds_i, 2048 * 6 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->bounds_out, 256)) != hipSuccess) return bail("hipMalloc", e);
+    *out = c;
+    return HVRT_OK;
+}
+
+void hvrt_destroy(hvrt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ranges, c->block_sums, c->stats, c->long_queue,
+                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters,
+                     c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* hvrt_last_error(const hvrt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+void* hvrt_stream(hvrt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int hvrt_synchronize(hvrt_ctx* c) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->render_pending) { c->tm.render_ms = ms_between(c->ev[6], c->ev[7]); c->render_pending = false; }
+    return HVRT_OK;
+}
+
+int hvrt_get_timings(const hvrt_ctx* c, hvrt_timings* out) {
+    if (!c || !out) return HVRT_ERR_INVALID;
+    *out = c->tm;
+    return HVRT_OK;
+}
+
+// ---- mesh ------------------------------------------------------------------------------------
+
+static int adopt_mesh(hvrt_ctx* c, const void* src, uint32_t n_tris, hipMemcpyKind kind) {
+    if (int r = bind(c)) return r;
+    if (n_tris && !src) return fail(c, HVRT_ERR_INVALID, "set_mesh: null triangle pointer");
+    if (kind == hipMemcpyDeviceToDevice && ((uintptr_t)src & 15))
+        return fail(c, HVRT_ERR_INVALID, "set_mesh_device: pointer must be 16-byte aligned");
+    if (int r = ensure<float>(c, c->tri_aos, c->aos_capacity, (uint64_t)n_tris * 12)) return r;
+    if (int r = ensure<float4>(c, c->tri_rec, c->rec_capacity, (uint64_t)n_tris * 3)) return r;
+    c->n_tris = n_tris;
+    c->has_grid = false;
+    if (n_tris) {
+        HIP_TRY(c, hipMemcpyAsync(c->tri_aos, src, (size_t)n_tris * 48, kind, c->stream));
+        HIP_TRY(c, launch_prepare_records(c->tri_aos, c->tri_rec, n_tris, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HVRT_OK;
+}
+
+int hvrt_set_mesh(hvrt_ctx* c, const float* tri_aos, uint32_t n_tris) {
+    if (!c) return HVRT_ERR_INVALID;
+    return adopt_mesh(c, tri_aos, n_tris, hipMemcpyHostToDevice);
+}
+
+int hvrt_set_mesh_device(hvrt_ctx* c, const void* d_tri_aos, uint32_t n_tris) {
+    if (!c) return HVRT_ERR_INVALID;
+    return adopt_mesh(c, d_tri_aos, n_tris, hipMemcpyDeviceToDevice);
+}
+
+static int run_bounds(hvrt_ctx* c, const float* d_pts, uint64_t n_points, float mn[3], float mx[3]) {
+    const int nb = bounds_blocks(n_points);
+    HIP_TRY(c, launch_bounds(d_pts, n_points, c->bounds_v, c->bounds_i, nb, c->bounds_out, c->stream));
+    float h[6];
+    HIP_TRY(c, hipMemcpyAsync(h, c->bounds_out, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(mn, h, 12);
+    memcpy(mx, h + 3, 12);
+    return HVRT_OK;
+}
+
+int hvrt_compute_bounds(hvrt_ctx* c, const float* pts, uint64_t n_points, float mn[3], float mx[3]) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (!mn || !mx || (n_points && !pts)) return fail(c, HVRT_ERR_INVALID, "compute_bounds: null pointer");
+    if (int r = bind(c)) return r;
+    if (int r = ensure_bytes(c, c->io_buf[0], c->io_cap[0], n_points * 12)) return r;
+    if (n_points) HIP_TRY(c, hipMemcpyAsync(c->io_buf[0], pts, n_points * 12, hipMemcpyHostToDevice, c->stream));
+    return run_bounds(c, (const float*)c->io_buf[0], n_points, mn, mx);
+}
+
+int hvrt_mesh_bounds(hvrt_ctx* c, float mn[3], float mx[3]) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (!mn || !mx) return fail(c, HVRT_ERR_INVALID, "mesh_bounds: null pointer");
+    if (int r = bind(c)) return r;
+    // corners of triangle t are floats [12t, 12t+9): run the point kernel over a strided view by
+    // packing them first would cost a pass; instead treat each triangle's first 9 floats as 3 points
+    // via a compact copy (device-to-device, 36 of every 48 bytes).
+    if (int r = ensure_bytes(c, c->io_buf[0], c->io_cap[0], (uint64_t)c->n_tris * 36)) return r;
+    if (c->n_tris)
+        HIP_TRY(c, hipMemcpy2DAsync(c->io_buf[0], 36, c->tri_aos, 48, 36, c->n_tris, hipMemcpyDeviceToDevice, c->stream));
+    return run_bounds(c, (const float*)c->io_buf[0], (uint64_t)c->n_tris * 3, mn, mx);
+}
+
+float hvrt_voxel_size(const float mn[3], const float mx[3], int nx, int ny, int nz) {
+    // SceneCreator.cpp:100-109 (std::max(a,b) = (a < b) ? b : a)
+    float gx = mx[0] - mn[0], gy = mx[1] - mn[1], gz = mx[2] - mn[2];
+    float m = gx < gy ? gy : gx;
+    m = m < gz ? gz : m;
+    int r = nx < ny ? ny : nx;
+    r = r < nz ? nz : r;
+    return m / (float)r;
+}
+
+// ---- grid ------------------------------------------------------------------------------------
+
+int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], const float mx[3], const float vs[3]) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (int r = check_grid_args(c, nx, ny, nz, mn, mx, vs)) return r;
+    if (!c->tri_aos && c->n_tris) return fail(c, HVRT_ERR_INVALID, "build_grid: no mesh");
+    c->has_grid = false;
+    set_grid_params(c, nx, ny, nz, mn, mx, vs);
+    const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox), n_chunks = npad / SCAN_CHUNK;
+
+    if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
+    if (int r = ensure<uint32_t>(c, c->ranges, c->ranges_capacity, (uint64_t)c->n_tris * 3)) return r;
+    if (int r = ensure<uint64_t>(c, c->block_sums, c->block_sums_capacity, n_chunks)) return r;
+
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[0], s));
+    HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(uint64_t), s));
+    HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, cnt_of(c), c->ranges, s));
+    HIP_TRY(c, hipEventRecord(c->ev[1], s));
+    HIP_TRY(c, launch_scan_reduce(cnt_of(c), n_chunks, c->block_sums, c->stats, s));
+    HIP_TRY(c, launch_scan_sums(c->block_sums, n_chunks, c->stats, s));
+    HIP_TRY(c, launch_scan_apply(cnt_of(c), n_chunks, c->block_sums, s));
+    HIP_TRY(c, hipEventRecord(c->ev[2], s));
+    uint64_t h_stats[4];
+    HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    const uint64_t total = h_stats[0];
+    if (total > 0xFFFFFFFFull)
+        return fail(c, HVRT_ERR_OVERFLOW, "build_grid: %llu triangle references exceed the u32 CSR", (unsigned long long)total);
+    if (int r = ensure<uint32_t>(c, c->indices, c->indices_capacity, total)) return r;
+    if (int r = ensure<uint32_t>(c, c->long_queue, c->long_queue_capacity, total / 33 + 1)) return r;
+
+    HIP_TRY(c, hipEventRecord(c->ev[3], s));
+    HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), c->indices, s));
+    HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    HIP_TRY(c, launch_sort(offsets_of(c), c->indices, nvox, c->long_queue, c->long_queue_capacity, c->stats, s));
+    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+
+    c->n_refs = total;
+    c->n_occupied = h_stats[1];
+    c->max_list = (uint32_t)h_stats[2];
+    c->has_grid = true;
+    c->tm.build_count_ms = ms_between(c->ev[0], c->ev[1]);
+    c->tm.build_scan_ms = ms_between(c->ev[1], c->ev[2]);
+    c->tm.build_fill_ms = ms_between(c->ev[3], c->ev[4]);
+    c->tm.build_sort_ms = ms_between(c->ev[4], c->ev[5]);
+    c->tm.build_total_ms = ms_between(c->ev[0], c->ev[5]);
+    return HVRT_OK;
+}
+
+static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], const float mx[3], const float vs[3],
+                     const void* offsets, const void* indices, uint64_t n_refs, hipMemcpyKind kind) {
+    if (int r = bind(c)) return r;
+    if (int r = check_grid_args(c, nx, ny, nz, mn, mx, vs)) return r;
+    if (!offsets || (n_refs && !indices)) return fail(c, HVRT_ERR_INVALID, "set_grid_csr: null array");
+    if (n_refs > 0xFFFFFFFFull) return fail(c, HVRT_ERR_OVERFLOW, "set_grid_csr: too many references");
+    c->has_grid = false;
+    set_grid_params(c, nx, ny, nz, mn, mx, vs);
+    const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox);
+    if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
+    if (int r = ensure<uint32_t>(c, c->indices, c->indices_capacity, n_refs)) return r;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemcpyAsync(offsets_of(c), offsets, (nvox + 1) * 4, kind, s));
+    if (n_refs) HIP_TRY(c, hipMemcpyAsync(c->indices, indices, n_refs * 4, kind, s));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(uint64_t), s));
+    HIP_TRY(c, launch_csr_stats(offsets_of(c), nvox, c->stats, s));
+    uint64_t h_stats[4];
+    HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->n_refs = n_refs;
+    c->n_occupied = h_stats[1];
+    c->max_list = (uint32_t)h_stats[2];
+    c->has_grid = true;
+    return HVRT_OK;
+}
+
+int hvrt_set_grid_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], const float mx[3], const float vs[3],
+                      const uint32_t* offsets, const uint32_t* indices) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (!offsets) return fail(c, HVRT_ERR_INVALID, "set_grid_csr: null offsets");
+    if (nx < 1 || ny < 1 || nz < 1) return fail(c, HVRT_ERR_INVALID, "grid: dimensions must be >= 1");
+    const uint64_t nvox = (uint64_t)nx * ny * nz;
+    return adopt_csr(c, nx, ny, nz, mn, mx, vs, offsets, indices, offsets[nvox], hipMemcpyHostToDevice);
+}
+
+int hvrt_set_grid_csr_device(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], const float mx[3],
+                             const float vs[3], const void* d_offsets, const void* d_indices, uint64_t n_refs) {
+    if (!c) return HVRT_ERR_INVALID;
+    return adopt_csr(c, nx, ny, nz, mn, mx, vs, d_offsets, d_indices, n_refs, hipMemcpyDeviceToDevice);
+}
+
+int hvrt_get_grid_info(const hvrt_ctx* c, hvrt_grid_info* out) {
+    if (!c || !out) return HVRT_ERR_INVALID;
+    if (!c->has_grid) return fail(const_cast<hvrt_ctx*>(c), HVRT_ERR_INVALID, "no grid");
+    out->nx = c->g.nx; out->ny = c->g.ny; out->nz = c->g.nz;
+    out->min_bound[0] = c->g.mnx; out->min_bound[1] = c->g.mny; out->min_bound[2] = c->g.mnz;
+    memcpy(out->max_bound, c->max_bound, 12);
+    out->voxel_size[0] = c->g.vsx; out->voxel_size[1] = c->g.vsy; out->voxel_size[2] = c->g.vsz;
+    out->n_voxels = c->g.nvox;
+    out->n_refs = c->n_refs;
+    out->n_occupied = c->n_occupied;
+    out->max_list = c->max_list;
+    out->n_triangles = c->n_tris;
+    return HVRT_OK;
+}
+
+int hvrt_get_csr(hvrt_ctx* c, uint32_t* offsets, uint32_t* indices) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "get_csr: no grid");
+    if (int r = bind(c)) return r;
+    if (offsets) HIP_TRY(c, hipMemcpyAsync(offsets, offsets_of(c), (c->g.nvox + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    if (indices && c->n_refs) HIP_TRY(c, hipMemcpyAsync(indices, c->indices, c->n_refs * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HVRT_OK;
+}
+
+int hvrt_get_device_arrays(hvrt_ctx* c, void** d_tri_aos, void** d_offsets, void** d_indices) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (d_tri_aos) *d_tri_aos = c->tri_aos;
+    if (d_offsets) *d_offsets = c->has_grid ? (void*)offsets_of(c) : nullptr;
+    if (d_indices) *d_indices = c->has_grid ? (void*)c->indices : nullptr;
+    return HVRT_OK;
+}
+
+// ---- rendering ---------------------------------------------------------------------------------
+
+void hvrt_make_camera_frame(const float pos[3], const float look_at[3], const float up_hint[3], float fov,
+                            float aspect, hvrt_camera_frame* out) {
+    // OctreeLikeRayTracer.cpp:342-359; this file is built with -ffp-contract=off
+    auto norm = [](float* v) {
+        float len = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (len > 0.0f) { v[0] = v[0] / len; v[1] = v[1] / len; v[2] = v[2] / len; }
+    };
+    auto crs = [](const float* a, const float* b, float* r) {
+        r[0] = a[1] * b[2] - a[2] * b[1];
+        r[1] = a[2] * b[0] - a[0] * b[2];
+        r[2] = a[0] * b[1] - a[1] * b[0];
+    };
+    float fov_rad = fov * 3.14159265f / 180.0f;
+    float half_h = tanf(fov_rad / 2.0f);
+    float half_w = aspect * half_h;
+    float fwd[3] = { look_at[0] - pos[0], look_at[1] - pos[1], look_at[2] - pos[2] };
+    norm(fwd);
+    float right[3];
+    crs(fwd, up_hint, right);
+    norm(right);
+    float up[3];
+    crs(right, fwd, up);
+    for (int k = 0; k < 3; ++k) {
+        out->origin[k] = pos[k];
+        out->horizontal[k] = right[k] * (2.0f * half_w);
+        out->vertical[k] = up[k] * (2.0f * half_h);
+    }
+    for (int k = 0; k < 3; ++k)
+        out->lower_left[k] = ((pos[k] - out->horizontal[k] * 0.5f) - out->vertical[k] * 0.5f) + fwd[k];
+}
+
+int hvrt_part_rows(int height, int tile_rows, int part, int n_parts) {
+    if (height <= 0 || tile_rows <= 0 || n_parts <= 0 || part < 0 || part >= n_parts) return 0;
+    const int n_tiles = (height + tile_rows - 1) / tile_rows;
+    int rows = 0;
+    for (int k = part; k < n_tiles; k += n_parts) {
+        int r = height - k * tile_rows;
+        rows += r < tile_rows ? r : tile_rows;
+    }
+    return rows;
+}
+
+int hvrt_render_part_device(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp,
+                            uint32_t seed, int tile_rows, int part, int n_parts, void* d_rgb, void* d_hit_id,
+                            void* d_t, void* d_counters) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (int r = require_scene(c)) return r;
+    if (!frame) return fail(c, HVRT_ERR_INVALID, "render: null camera frame");
+    if (width < 1 || height < 1 || (uint64_t)width * height > 0x7FFFFFFFull)
+        return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
+    if (spp < 1) return fail(c, HVRT_ERR_INVALID, "render: spp must be >= 1");
+    if (tile_rows < 1 || n_parts < 1 || part < 0 || part >= n_parts)
+        return fail(c, HVRT_ERR_INVALID, "render: bad partition (tile_rows %d, part %d of %d)", tile_rows, part, n_parts);
+    RenderArgs ra;
+    ra.frame = *frame;
+    ra.width = width; ra.height = height; ra.spp = spp; ra.seed = seed;
+    ra.tile_rows = tile_rows; ra.part = part; ra.n_parts = n_parts;
+    ra.local_rows = hvrt_part_rows(height, tile_rows, part, n_parts);
+    ra.rgb = (float*)d_rgb; ra.hit_id = (uint32_t*)d_hit_id; ra.t = (float*)d_t;
+    ra.counters = (unsigned long long*)d_counters;
+    ra.tile_counter = c->tile_counter;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, sizeof(uint32_t), s));
+    HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, s));
+    HIP_TRY(c, hipEventRecord(c->ev[7], s));
+    c->render_pending = true;
+    return HVRT_OK;
+}
+
+int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,
+                float* rgb, uint32_t* hit_id, float* t, uint64_t counters[2]) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (width < 1 || height < 1) return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
+    const uint64_t npx = (uint64_t)width * height;
+    if (rgb) if (int r = ensure_bytes(c, c->out_buf[0], c->out_cap[0], npx * 12)) return r;
+    if (hit_id) if (int r = ensure_bytes(c, c->out_buf[1], c->out_cap[1], npx * 4)) return r;
+    if (t) if (int r = ensure_bytes(c, c->out_buf[2], c->out_cap[2], npx * 4)) return r;
+    hipStream_t s = c->stream;
+    if (counters) HIP_TRY(c, hipMemsetAsync(c->counters, 0, 16, s));
+    if (int r = hvrt_render_part_device(c, frame, width, height, spp, seed, height, 0, 1,
+                                        rgb ? c->out_buf[0] : nullptr, hit_id ? c->out_buf[1] : nullptr,
+                                        t ? c->out_buf[2] : nullptr, counters ? c->counters : nullptr)) return r;
+    if (rgb) HIP_TRY(c, hipMemcpyAsync(rgb, c->out_buf[0], npx * 12, hipMemcpyDeviceToHost, s));
+    if (hit_id) HIP_TRY(c, hipMemcpyAsync(hit_id, c->out_buf[1], npx * 4, hipMemcpyDeviceToHost, s));
+    if (t) HIP_TRY(c, hipMemcpyAsync(t, c->out_buf[2], npx * 4, hipMemcpyDeviceToHost, s));
+    if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->tm.render_ms = ms_between(c->ev[6], c->ev[7]);
+    c->render_pending = false;
+    return HVRT_OK;
+}
+
+int hvrt_assemble_parts_device(hvrt_ctx* c, const void* d_parts, int width, int height, int tile_rows, int n_parts,
+                               int slab_rows, int bytes_per_pixel, void* d_frame) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (!d_parts || !d_frame) return fail(c, HVRT_ERR_INVALID, "assemble: null pointer");
+    if (width < 1 || height < 1 || tile_rows < 1 || n_parts < 1 || bytes_per_pixel < 4 || (bytes_per_pixel & 3))
+        return fail(c, HVRT_ERR_INVALID, "assemble: bad geometry");
+    for (int p = 0; p < n_parts; ++p)
+        if (hvrt_part_rows(height, tile_rows, p, n_parts) > slab_rows)
+            return fail(c, HVRT_ERR_INVALID, "assemble: slab_rows %d too small for part %d", slab_rows, p);
+    HIP_TRY(c, launch_assemble(d_parts, width, height, tile_rows, n_parts, slab_rows, bytes_per_pixel, d_frame, c->stream));
+    return HVRT_OK;
+}
+
+int hvrt_trace(hvrt_ctx* c, const float* origins, const float* dirs, uint32_t n, hvrt_hit* out, uint64_t counters[2]) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (int r = require_scene(c)) return r;
+    if (n && (!origins || !dirs || !out)) return fail(c, HVRT_ERR_INVALID, "trace: null pointer");
+    if (int r = ensure_bytes(c, c->io_buf[0], c->io_cap[0], (uint64_t)n * 12)) return r;
+    if (int r = ensure_bytes(c, c->io_buf[1], c->io_cap[1], (uint64_t)n * 12)) return r;
+    if (int r = ensure_bytes(c, c->io_buf[2], c->io_cap[2], (uint64_t)n * sizeof(hvrt_hit))) return r;
+    hipStream_t s = c->stream;
+    if (counters) HIP_TRY(c, hipMemsetAsync(c->counters, 0, 16, s));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->io_buf[0], origins, (size_t)n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemcpyAsync(c->io_buf[1], dirs, (size_t)n * 12, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipEventRecord(c->ev[6], s));
+        HIP_TRY(c, launch_trace(scene_of(c), (const float*)c->io_buf[0], (const float*)c->io_buf[1], n,
+                                (hvrt_hit*)c->io_buf[2], counters ? c->counters : nullptr, s));
+        HIP_TRY(c, hipEventRecord(c->ev[7], s));
+        HIP_TRY(c, hipMemcpyAsync(out, c->io_buf[2], (size_t)n * sizeof(hvrt_hit), hipMemcpyDeviceToHost, s));
+    }
+    if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (n) c->tm.trace_ms = ms_between(c->ev[6], c->ev[7]);
+    return HVRT_OK;
+}
+
+}  // extern "C"

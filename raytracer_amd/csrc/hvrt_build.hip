@@ -1,0 +1,511 @@
+// hvrt_build.hip -- voxel-grid build kernels for gfx950 (MI355X).
+//
+// Replaces the reference's voxelizeTrianglesDirect (SceneCreator.cpp:197-281) and its dead GPU /
+// inline variants (SceneCreator.cu:67-358, InlineVoxelizer.h:17-167) with:
+//   k_count       one lane per triangle: AABB -> inclusive voxel range (SceneCreator.cpp:23-37,
+//                 177-188, GeometryUtils.cpp:43-51), atomic count per voxel; big ranges are spread
+//                 over the whole wave
+//   k_scan_*      exclusive scan of the counts in flat order ix + nx*(iy + ny*iz) (three phases:
+//                 per-chunk reduce, scan of chunk sums, per-chunk wave-level scan + apply)
+//   k_fill        scatter of triangle ids through atomic cursors (the scanned counts themselves:
+//                 after the fill cnt[v] == start(v+1), i.e. the buffer IS the CSR offsets array
+//                 shifted by one, so no separate cursor array and no copy)
+//   k_sort_*      per-voxel ascending order (the reference appends in ascending triangle order,
+//                 SceneCreator.cpp:212-230): insertion sort for short lists, LDS bitonic network
+//                 for long ones, global-memory bitonic beyond the LDS capacity
+// All integer / byte work; HBM-bound; no MFMA.  Compile with -ffp-contract=off.
+#include "hvrt_internal.hpp"
+
+#include <float.h>
+#include <limits.h>
+
+namespace hvrt {
+namespace {
+
+// static_cast<int>(float) with x86 cvttss2si semantics (NaN / out of range -> INT_MIN): the
+// reference's platform behaviour, spelled out because v_cvt_i32_f32 saturates instead.
+__device__ __forceinline__ int f2i(float f) {
+    return (!(f < 2147483648.0f) || f < -2147483648.0f) ? INT_MIN : (int)f;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// std::min / std::max as libstdc++ / MSVC define them (GeometryUtils.cpp:44-50 nests them).
+__device__ __forceinline__ float min2(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float max2(float a, float b) { return a < b ? b : a; }
+
+__device__ __forceinline__ uint64_t flat_index(const GridParams& g, int ix, int iy, int iz) {
+    return (uint64_t)ix + (uint64_t)g.nx * ((uint64_t)iy + (uint64_t)g.ny * (uint64_t)iz);
+}
+
+// ------------------------------------------------------------------------------------------
+// records: v0, e1, e2, normal
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prepare_records(const float4* __restrict__ aos,
+                                                         float4* __restrict__ rec, uint32_t T) {
+    uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= T) return;
+    float4 a = aos[3ull * t], b = aos[3ull * t + 1], c = aos[3ull * t + 2];
+    // a = v0.xyz v1.x | b = v1.yz v2.xy | c = v2.z n.xyz
+    float e1x = a.w - a.x, e1y = b.x - a.y, e1z = b.y - a.z;   // subtract(v1, v0), GeometryUtils.cpp:66
+    float e2x = b.z - a.x, e2y = b.w - a.y, e2z = c.x - a.z;   // subtract(v2, v0), GeometryUtils.cpp:67
+    rec[3ull * t]     = make_float4(a.x, a.y, a.z, e1x);
+    rec[3ull * t + 1] = make_float4(e1y, e1z, e2x, e2y);
+    rec[3ull * t + 2] = make_float4(e2z, c.y, c.z, c.w);
+}
+
+// ------------------------------------------------------------------------------------------
+// count / fill
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t SMALL_VOL = 32;  // ranges up to this many voxels are walked by the owning lane
+
+template <bool FILL>
+__device__ __forceinline__ void touch(uint32_t* cnt, uint32_t* indices, uint64_t f, uint32_t t) {
+    if (FILL) {
+        uint32_t p = atomicAdd(&cnt[f], 1u);
+        indices[p] = t;
+    } else {
+        atomicAdd(&cnt[f], 1u);
+    }
+}
+
+template <bool FILL>
+__device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, uint32_t* indices, uint32_t t,
+                                           bool valid, int lx, int ly, int lz, int hx, int hy, int hz) {
+    const uint32_t dx = valid ? (uint32_t)(hx - lx + 1) : 0u;
+    const uint32_t dy = valid ? (uint32_t)(hy - ly + 1) : 0u;
+    const uint32_t dz = valid ? (uint32_t)(hz - lz + 1) : 0u;
+    const uint64_t vol = (uint64_t)dx * dy * dz;
+    const bool big = vol > SMALL_VOL;
+    if (valid && !big) {
+        for (int iz = lz; iz <= hz; ++iz)
+            for (int iy = ly; iy <= hy; ++iy)
+                for (int ix = lx; ix <= hx; ++ix) touch<FILL>(cnt, indices, flat_index(g, ix, iy, iz), t);
+    }
+    // Triangles that span many voxels: the whole wave walks each one (every lane reaches here).
+    unsigned long long m = __ballot(big);
+    const int lane = threadIdx.x & 63;
+    while (m) {
+        const int src = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        const int blx = __shfl(lx, src), bly = __shfl(ly, src), blz = __shfl(lz, src);
+        const uint32_t bdx = __shfl(dx, src), bdy = __shfl(dy, src), bdz = __shfl(dz, src);
+        const uint32_t bt = __shfl(t, src);
+        const uint64_t bvol = (uint64_t)bdx * bdy * bdz;
+        const uint64_t plane = (uint64_t)bdx * bdy;
+        for (uint64_t i = lane; i < bvol; i += 64) {
+            const uint32_t iz = (uint32_t)(i / plane);
+            const uint32_t r = (uint32_t)(i - (uint64_t)iz * plane);
+            const uint32_t iy = r / bdx, ix = r - iy * bdx;
+            touch<FILL>(cnt, indices, flat_index(g, blx + (int)ix, bly + (int)iy, blz + (int)iz), bt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, uint32_t T, GridParams g,
+                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ ranges) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool valid = t < T;
+    int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
+    if (valid) {
+        float4 a = aos[3ull * t], b = aos[3ull * t + 1], c = aos[3ull * t + 2];
+        // computeTriangleMinMax, GeometryUtils.cpp:43-51
+        float mnx = min2(min2(a.x, a.w), b.z), mny = min2(min2(a.y, b.x), b.w), mnz = min2(min2(a.z, b.y), c.x);
+        float mxx = max2(max2(a.x, a.w), b.z), mxy = max2(max2(a.y, b.x), b.w), mxz = max2(max2(a.z, b.y), c.x);
+        // worldToVoxelIndex, SceneCreator.cpp:23-37: IEEE divide, truncate, clamp
+        lx = clampi(f2i((mnx - g.mnx) / g.vsx), 0, g.nx - 1);
+        ly = clampi(f2i((mny - g.mny) / g.vsy), 0, g.ny - 1);
+        lz = clampi(f2i((mnz - g.mnz) / g.vsz), 0, g.nz - 1);
+        hx = clampi(f2i((mxx - g.mnx) / g.vsx), 0, g.nx - 1);
+        hy = clampi(f2i((mxy - g.mny) / g.vsy), 0, g.ny - 1);
+        hz = clampi(f2i((mxz - g.mnz) / g.vsz), 0, g.nz - 1);
+        // A NaN corner can make lo > hi: the reference's loops then run zero times; keep that.
+        ranges[3ull * t]     = (uint32_t)lx | ((uint32_t)hx << 16);
+        ranges[3ull * t + 1] = (uint32_t)ly | ((uint32_t)hy << 16);
+        ranges[3ull * t + 2] = (uint32_t)lz | ((uint32_t)hz << 16);
+    }
+    const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
+    walk_range<false>(g, cnt, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
+}
+
+__global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ ranges, uint32_t T, GridParams g,
+                                              uint32_t* __restrict__ cnt, uint32_t* __restrict__ indices) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const bool valid = t < T;
+    int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
+    if (valid) {
+        uint32_t rx = ranges[3ull * t], ry = ranges[3ull * t + 1], rz = ranges[3ull * t + 2];
+        lx = (int)(rx & 0xFFFFu); hx = (int)(rx >> 16);
+        ly = (int)(ry & 0xFFFFu); hy = (int)(ry >> 16);
+        lz = (int)(rz & 0xFFFFu); hz = (int)(rz >> 16);
+    }
+    const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
+    walk_range<true>(g, cnt, indices, t, nonempty, lx, ly, lz, hx, hy, hz);
+}
+
+// ------------------------------------------------------------------------------------------
+// scan (wave-level primitives)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { uint32_t o = __shfl_down(v, d); v = o > v ? o : v; }
+    return v;
+}
+
+// phase A: per-chunk sum (+ occupancy statistics, VoxelizationResult::occupied_count)
+__global__ __launch_bounds__(256) void k_scan_reduce(const uint4* __restrict__ cnt4, uint64_t* __restrict__ block_sums,
+                                                     uint64_t* __restrict__ stats) {
+    const uint64_t c = blockIdx.x;
+    const uint4* p = cnt4 + c * (SCAN_CHUNK / 4);
+    uint64_t sum = 0; uint32_t occ = 0, mx = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint4 v = p[j * 256 + threadIdx.x];
+        sum += (uint64_t)v.x + v.y + v.z + v.w;
+        occ += (v.x > 0) + (v.y > 0) + (v.z > 0) + (v.w > 0);
+        uint32_t m = v.x > v.y ? v.x : v.y, n = v.z > v.w ? v.z : v.w;
+        m = m > n ? m : n;
+        mx = mx > m ? mx : m;
+    }
+    __shared__ uint64_t s_sum[4], s_occ[4];
+    __shared__ uint32_t s_mx[4];
+    sum = wave_sum64(sum);
+    uint64_t occ64 = wave_sum64(occ);
+    mx = wave_max32(mx);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_sum[w] = sum; s_occ[w] = occ64; s_mx[w] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t ts = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        uint64_t to = s_occ[0] + s_occ[1] + s_occ[2] + s_occ[3];
+        uint32_t tm = s_mx[0];
+        for (int i = 1; i < 4; ++i) tm = s_mx[i] > tm ? s_mx[i] : tm;
+        block_sums[c] = ts;
+        if (to) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)to);
+        if (tm) atomicMax((unsigned long long*)&stats[2], (unsigned long long)tm);
+    }
+}
+
+// phase B: exclusive scan of the chunk sums by one workgroup
+__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ block_sums, uint64_t n,
+                                                    uint64_t* __restrict__ stats) {
+    __shared__ uint64_t s[1024];
+    const uint64_t per = (n + 1023) / 1024;
+    const uint64_t b = threadIdx.x * per;
+    const uint64_t e = b + per < n ? b + per : n;
+    uint64_t sum = 0;
+    for (uint64_t i = b; i < e; ++i) sum += block_sums[i];
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint64_t o = threadIdx.x >= (unsigned)d ? s[threadIdx.x - d] : 0;
+        __syncthreads();
+        s[threadIdx.x] += o;
+        __syncthreads();
+    }
+    uint64_t run = s[threadIdx.x] - sum;
+    for (uint64_t i = b; i < e; ++i) { uint64_t v = block_sums[i]; block_sums[i] = run; run += v; }
+    if (threadIdx.x == 1023) stats[0] = s[1023];
+}
+
+// phase C: per-chunk exclusive scan, in place
+__global__ __launch_bounds__(256) void k_scan_apply(uint4* __restrict__ cnt4, const uint64_t* __restrict__ block_sums) {
+    const uint64_t c = blockIdx.x;
+    uint4* p = cnt4 + c * (SCAN_CHUNK / 4) + threadIdx.x * 4;
+    uint4 v[4];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = p[j]; tot += v[j].x + v[j].y + v[j].z + v[j].w; }
+    __shared__ uint32_t s_w[4];
+    uint32_t inc = wave_inclusive_scan(tot);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = (uint32_t)block_sums[c];
+    for (int i = 0; i < w; ++i) base += s_w[i];
+    uint32_t run = base + inc - tot;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint4 o;
+        o.x = run; run += v[j].x;
+        o.y = run; run += v[j].y;
+        o.z = run; run += v[j].z;
+        o.w = run; run += v[j].w;
+        p[j] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-voxel ascending order
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t SORT_SMALL = 32;      // insertion sort by the owning lane up to here
+constexpr uint32_t SORT_MID = 4096;      // static-LDS bitonic (16 KiB)
+constexpr uint32_t SORT_BIG = 32768;     // dynamic-LDS bitonic (128 KiB of the CU's 160 KiB)
+
+__global__ __launch_bounds__(256) void k_sort_small(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ indices,
+                                                    uint64_t nvox, uint32_t* __restrict__ queue, uint64_t queue_cap,
+                                                    uint64_t* __restrict__ stats) {
+    const uint64_t v = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (v >= nvox) return;
+    const uint32_t b0 = offsets[v], b1 = offsets[v + 1];
+    const uint32_t len = b1 - b0;
+    if (len <= 1) return;
+    if (len <= SORT_SMALL) {
+        uint32_t* a = indices + b0;
+        for (uint32_t i = 1; i < len; ++i) {
+            uint32_t key = a[i];
+            uint32_t j = i;
+            while (j > 0) {
+                uint32_t prev = a[j - 1];
+                if (prev <= key) break;
+                a[j] = prev;
+                --j;
+            }
+            if (j != i) a[j] = key;
+        }
+    } else {
+        unsigned long long slot = atomicAdd((unsigned long long*)&stats[3], 1ull);
+        if (slot < queue_cap) queue[slot] = (uint32_t)v;
+    }
+}
+
+// Bitonic network for arbitrary n with every comparator ascending ("flip" first stage of each
+// merge): elements at positions >= n act as +inf and never move, so no padding is stored.
+template <typename Ptr>
+__device__ __forceinline__ void bitonic_any_n(Ptr a, uint32_t n, uint32_t tid, uint32_t nthreads) {
+    uint32_t P = 1;
+    while (P < n) P <<= 1;
+    const uint32_t half = P >> 1;
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+        // flip: i and its mirror inside blocks of k
+        for (uint32_t c = tid; c < half; c += nthreads) {
+            uint32_t grp = c / (k >> 1), w = c % (k >> 1);
+            uint32_t i = grp * k + w, j = grp * k + (k - 1 - w);
+            if (j < n) { uint32_t x = a[i], y = a[j]; if (x > y) { a[i] = y; a[j] = x; } }
+        }
+        __syncthreads();
+        for (uint32_t d = k >> 2; d > 0; d >>= 1) {
+            for (uint32_t c = tid; c < half; c += nthreads) {
+                uint32_t grp = c / d, w = c % d;
+                uint32_t i = grp * 2 * d + w, j = i + d;
+                if (j < n) { uint32_t x = a[i], y = a[j]; if (x > y) { a[i] = y; a[j] = x; } }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// TIER 0: 33..4096 (static LDS), 1: 4097..32768 (dynamic LDS), 2: above (in global memory)
+template <int TIER, int NT>
+__global__ __launch_bounds__(NT) void k_sort_long(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ indices,
+                                                  const uint32_t* __restrict__ queue, uint64_t queue_cap,
+                                                  const uint64_t* __restrict__ stats) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint32_t s_static[TIER == 0 ? SORT_MID : 1];
+    uint32_t* lds = TIER == 0 ? s_static : s_dyn;
+    uint64_t qn = stats[3];
+    if (qn > queue_cap) qn = queue_cap;
+    for (uint64_t q = blockIdx.x; q < qn; q += gridDim.x) {
+        const uint32_t v = queue[q];
+        const uint32_t b0 = offsets[v], b1 = offsets[(uint64_t)v + 1];
+        const uint32_t len = b1 - b0;
+        const bool mine = TIER == 0 ? (len <= SORT_MID)
+                        : TIER == 1 ? (len > SORT_MID && len <= SORT_BIG)
+                                    : (len > SORT_BIG);
+        if (!mine) continue;   // uniform over the workgroup
+        uint32_t* a = indices + b0;
+        if (TIER == 2) {
+            bitonic_any_n(a, len, threadIdx.x, NT);
+        } else {
+            for (uint32_t i = threadIdx.x; i < len; i += NT) lds[i] = a[i];
+            __syncthreads();
+            bitonic_any_n(lds, len, threadIdx.x, NT);
+            for (uint32_t i = threadIdx.x; i < len; i += NT) a[i] = lds[i];
+            __syncthreads();
+        }
+    }
+}
+
+// occupancy statistics of an ingested CSR (hvrt_set_grid_csr*)
+__global__ __launch_bounds__(256) void k_csr_stats(const uint32_t* __restrict__ offsets, uint64_t nvox,
+                                                   uint64_t* __restrict__ stats) {
+    uint64_t occ = 0; uint32_t mx = 0;
+    for (uint64_t v = (uint64_t)blockIdx.x * 256u + threadIdx.x; v < nvox; v += (uint64_t)gridDim.x * 256u) {
+        uint32_t len = offsets[v + 1] - offsets[v];
+        occ += len > 0;
+        mx = len > mx ? len : mx;
+    }
+    occ = wave_sum64(occ);
+    mx = wave_max32(mx);
+    if ((threadIdx.x & 63) == 0) {
+        if (occ) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)occ);
+        if (mx) atomicMax((unsigned long long*)&stats[2], (unsigned long long)mx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// mesh bounds (computeMeshBounds, SceneCreator.cpp:49-84)
+// ------------------------------------------------------------------------------------------
+// The reference folds sequentially with `if (c < mn) mn = c` from +FLT_MAX (and the mirror image for
+// max from -FLT_MAX): NaNs and infinities never enter, and among equal minima (+0 / -0) the first
+// in vertex order wins.  Carrying (value, first index) makes that an order-free reduction.
+struct MinMax6 {
+    float v[6];
+    uint64_t i[6];
+};
+__device__ __forceinline__ void mm_init(MinMax6& m) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { m.v[k] = FLT_MAX; m.v[3 + k] = -FLT_MAX; m.i[k] = ~0ull; m.i[3 + k] = ~0ull; }
+}
+__device__ __forceinline__ void mm_take(MinMax6& m, int k, float v, uint64_t i) {
+    if (k < 3) { if (v < m.v[k] || (v == m.v[k] && i < m.i[k])) { m.v[k] = v; m.i[k] = i; } }
+    else       { if (m.v[k] < v || (v == m.v[k] && i < m.i[k])) { m.v[k] = v; m.i[k] = i; } }
+}
+__device__ __forceinline__ void mm_wave_reduce(MinMax6& m) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            float ov = __shfl_down(m.v[k], d);
+            uint64_t oi = __shfl_down(m.i[k], d);
+            mm_take(m, k, ov, oi);
+        }
+    }
+}
+__device__ __forceinline__ void mm_block_reduce_store(MinMax6& m, float* out_v, uint64_t* out_i) {
+    __shared__ float s_v[4][6];
+    __shared__ uint64_t s_i[4][6];
+    mm_wave_reduce(m);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { s_v[w][k] = m.v[k]; s_i[w][k] = m.i[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int ww = 1; ww < 4; ++ww)
+            for (int k = 0; k < 6; ++k) mm_take(m, k, s_v[ww][k], s_i[ww][k]);
+        for (int k = 0; k < 6; ++k) { out_v[k] = m.v[k]; out_i[k] = m.i[k]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bounds_partial(const float* __restrict__ pts, uint64_t n_points,
+                                                        float* __restrict__ part_v, uint64_t* __restrict__ part_i) {
+    MinMax6 m;
+    mm_init(m);
+    const uint64_t n_floats = n_points * 3;
+    for (uint64_t e = (uint64_t)blockIdx.x * 256u + threadIdx.x; e < n_floats; e += (uint64_t)gridDim.x * 256u) {
+        const float c = pts[e];
+        const uint64_t pi = e / 3;
+        const int k = (int)(e - pi * 3);
+        const float cmin = (c < FLT_MAX) ? c : FLT_MAX;      // what a sequential fold could ever hold
+        const float cmax = (-FLT_MAX < c) ? c : -FLT_MAX;
+        if (k == 0)      { mm_take(m, 0, cmin, pi); mm_take(m, 3, cmax, pi); }
+        else if (k == 1) { mm_take(m, 1, cmin, pi); mm_take(m, 4, cmax, pi); }
+        else             { mm_take(m, 2, cmin, pi); mm_take(m, 5, cmax, pi); }
+    }
+    mm_block_reduce_store(m, part_v + 6ull * blockIdx.x, part_i + 6ull * blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_bounds_final(const float* __restrict__ part_v, const uint64_t* __restrict__ part_i,
+                                                      int n_parts, float* __restrict__ out6) {
+    MinMax6 m;
+    mm_init(m);
+    for (int p = threadIdx.x; p < n_parts; p += 256)
+        for (int k = 0; k < 6; ++k) mm_take(m, k, part_v[6 * p + k], part_i[6 * p + k]);
+    __shared__ uint64_t dummy_i[6];
+    mm_block_reduce_store(m, out6, dummy_i);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t T, hipStream_t s) {
+    if (T == 0) return hipSuccess;
+    k_prepare_records<<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, tri_rec, T);
+    return hipGetLastError();
+}
+
+hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* ranges,
+                        hipStream_t s) {
+    if (T == 0) return hipSuccess;
+    k_count<<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_reduce(const uint32_t* cnt, uint64_t n_chunks, uint64_t* block_sums, uint64_t* stats,
+                              hipStream_t s) {
+    k_scan_reduce<<<(unsigned)n_chunks, 256, 0, s>>>((const uint4*)cnt, block_sums, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_sums(uint64_t* block_sums, uint64_t n_chunks, uint64_t* stats, hipStream_t s) {
+    k_scan_sums<<<1, 1024, 0, s>>>(block_sums, n_chunks, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_apply(uint32_t* cnt, uint64_t n_chunks, const uint64_t* block_sums, hipStream_t s) {
+    k_scan_apply<<<(unsigned)n_chunks, 256, 0, s>>>((uint4*)cnt, block_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill(const uint32_t* ranges, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* indices,
+                       hipStream_t s) {
+    if (T == 0) return hipSuccess;
+    k_fill<<<(T + 255) / 256, 256, 0, s>>>(ranges, T, g, cnt, indices);
+    return hipGetLastError();
+}
+
+hipError_t launch_sort(const uint32_t* offsets, uint32_t* indices, uint64_t nvox, uint32_t* queue, uint64_t queue_cap,
+                       uint64_t* stats, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_sort_long<1, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)(SORT_BIG * sizeof(uint32_t)));
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    k_sort_small<<<(unsigned)((nvox + 255) / 256), 256, 0, s>>>(offsets, indices, nvox, queue, queue_cap, stats);
+    k_sort_long<0, 256><<<2048, 256, 0, s>>>(offsets, indices, queue, queue_cap, stats);
+    k_sort_long<1, 1024><<<256, 1024, SORT_BIG * sizeof(uint32_t), s>>>(offsets, indices, queue, queue_cap, stats);
+    k_sort_long<2, 1024><<<256, 1024, 0, s>>>(offsets, indices, queue, queue_cap, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s) {
+    uint64_t blocks = (nvox + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    k_csr_stats<<<(unsigned)blocks, 256, 0, s>>>(offsets, nvox, stats);
+    return hipGetLastError();
+}
+
+int bounds_blocks(uint64_t n_points) {
+    uint64_t b = (n_points * 3 + 256 * 16 - 1) / (256 * 16);
+    if (b < 1) b = 1;
+    if (b > 2048) b = 2048;
+    return (int)b;
+}
+
+hipError_t launch_bounds(const float* pts, uint64_t n_points, float* part_v, uint64_t* part_i, int n_blocks,
+                         float* out6, hipStream_t s) {
+    k_bounds_partial<<<n_blocks, 256, 0, s>>>(pts, n_points, part_v, part_i);
+    k_bounds_final<<<1, 256, 0, s>>>(part_v, part_i, n_blocks, out6);
+    return hipGetLastError();
+}
+
+}  // namespace hvrt

@@ -1,0 +1,87 @@
+// hvrt_internal.hpp -- shared between the libhvrt translation units (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hvrt.h"
+
+namespace hvrt {
+
+// Grid geometry as the kernels see it.  Flat voxel index f = ix + nx*(iy + ny*iz)
+// (reference: SceneCreator.cpp:40-42).
+struct GridParams {
+    int nx, ny, nz;
+    float mnx, mny, mnz;   // VoxelGrid::minBound
+    float vsx, vsy, vsz;   // VoxelGrid::voxelSize (uniform when built by us)
+    uint64_t nvox;
+};
+
+// HBM layout of the scene (all owned by the context):
+//   tri_aos   T x 12 f32   v0,v1,v2,normal  -- the reference's Triangle (Voxels.h:10-13); input of the
+//                                              voxelizer, and what is broadcast/returned
+//   tri_rec   T x 12 f32   v0,e1,e2,normal  -- traversal record: e1 = v1-v0, e2 = v2-v0 precomputed
+//                                              (same fp32 subtractions Moller-Trumbore would do per test)
+//   offsets   nvox+1 u32   CSR exclusive scan; lives at cnt_base+3 so that cnt = offsets+1 is 16-B aligned
+//   indices   n_refs u32   ascending per voxel
+struct SceneDev {
+    GridParams g;
+    const float4* tri_rec;
+    const uint32_t* offsets;
+    const uint32_t* indices;
+    uint32_t n_tris;
+};
+
+struct RenderArgs {
+    hvrt_camera_frame frame;
+    int width, height;       // full frame
+    int spp;
+    uint32_t seed;
+    int tile_rows, part, n_parts;
+    int local_rows;          // rows owned by this part
+    float* rgb;              // local_rows x width x 3 (nullable)
+    uint32_t* hit_id;        // nullable
+    float* t;                // nullable
+    unsigned long long* counters;  // 2 x u64, nullable
+    uint32_t* tile_counter;  // persistent-thread work queue head (zeroed before launch)
+};
+
+// ---- launchers (hvrt_build.hip) ----
+struct BuildScratch {
+    uint32_t* cnt_base;        // nvox_padded + 8 u32
+    uint64_t cnt_capacity;     // in u32
+    uint32_t* ranges;          // T x 3 u32 (lo | hi << 16 per axis)
+    uint64_t ranges_capacity;  // in triangles
+    uint64_t* block_sums;      // scan partials
+    uint64_t block_sums_capacity;
+    uint64_t* stats;           // [0]=total refs, [1]=occupied, [2]=max list, [3]=long-queue length
+    uint32_t* long_queue;
+    uint64_t long_queue_capacity;
+};
+
+constexpr int SCAN_CHUNK = 4096;  // elements per scan block (256 threads x 16)
+
+hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t n_tris, hipStream_t s);
+hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
+                        uint32_t* ranges, hipStream_t s);
+hipError_t launch_scan_reduce(const uint32_t* cnt, uint64_t n_chunks, uint64_t* block_sums, uint64_t* stats,
+                              hipStream_t s);
+hipError_t launch_scan_sums(uint64_t* block_sums, uint64_t n_chunks, uint64_t* stats, hipStream_t s);
+hipError_t launch_scan_apply(uint32_t* cnt, uint64_t n_chunks, const uint64_t* block_sums, hipStream_t s);
+hipError_t launch_fill(const uint32_t* ranges, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
+                       uint32_t* indices, hipStream_t s);
+hipError_t launch_sort(const uint32_t* offsets, uint32_t* indices, uint64_t nvox, uint32_t* long_queue,
+                       uint64_t long_queue_capacity, uint64_t* stats, hipStream_t s);
+hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s);
+hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* blocks x 6 + idx */,
+                         uint64_t* partial_idx, int n_blocks, float* out6, hipStream_t s);
+int bounds_blocks(uint64_t n_points);
+
+// ---- launchers (hvrt_trace.hip) ----
+hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s);
+hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n,
+                        hvrt_hit* out, unsigned long long* counters, hipStream_t s);
+hipError_t launch_assemble(const void* parts, int width, int height, int tile_rows, int n_parts,
+                           int slab_rows, int bytes_per_pixel, void* frame, hipStream_t s);
+
+}  // namespace hvrt

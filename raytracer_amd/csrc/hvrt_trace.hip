@@ -1,0 +1,280 @@
+// hvrt_trace.hip -- primary-ray grid traversal kernels for gfx950 (MI355X).
+//
+// Replaces OctreeLikeRayTracer::render / traceRay (OctreeLikeRayTracer.cpp:88-126) with a
+// persistent-thread kernel: waves pull 8x8 pixel tiles from a work-queue head, every lane runs
+// the reference's Amanatides-Woo 3D-DDA (OctreeLikeRayTracer.cpp:155-260, 309-336) and
+// Moller-Trumbore test (GeometryUtils.cpp:57-97) with the reference's exact fp32 operation order,
+// NaN/inf control flow included, then shades (OctreeLikeRayTracer.cpp:27-40,
+// Shaders.cpp:4-22).  Compile with -ffp-contract=off: a*b+c must stay v_mul + v_add.
+#include "hvrt_internal.hpp"
+
+#include <float.h>
+#include <limits.h>
+
+namespace hvrt {
+namespace {
+
+constexpr float EPS = FLT_EPSILON;   // GeometryUtils.cpp:64
+
+__device__ __forceinline__ int f2i(float f) {
+    return (!(f < 2147483648.0f) || f < -2147483648.0f) ? INT_MIN : (int)f;
+}
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+__device__ __forceinline__ V3 add(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ V3 mul(V3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }   // ((ax*bx)+(ay*by))+(az*bz)
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+    return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+// VectorMath.h:9-15
+__device__ __forceinline__ V3 normalize(V3 v) {
+    float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    if (len > 0.0f) return { v.x / len, v.y / len, v.z / len };
+    return v;
+}
+
+// GeometryUtils.cpp:57-97 on a (v0, e1, e2) record.
+__device__ __forceinline__ bool ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t_out) {
+    V3 p = cross(d, e2);
+    float det = dot(e1, p);
+    if (det > -EPS && det < EPS) return false;
+    float inv = 1.0f / det;   // == (float)(1.0 / (double)det): double rounding is innocuous for 53 >= 2*24+2
+    V3 s = sub(o, v0);
+    float u = inv * dot(s, p);
+    if ((u < 0.0f && fabsf(u) > EPS) || (u > 1.0f && fabsf(u - 1.0f) > EPS)) return false;
+    V3 q = cross(s, e1);
+    float v = inv * dot(d, q);
+    if ((v < 0.0f && fabsf(v) > EPS) || (u + v > 1.0f && fabsf(u + v - 1.0f) > EPS)) return false;
+    float t = inv * dot(e2, q);
+    t_out = t;
+    return t > EPS;
+}
+
+struct TraceResult {
+    uint32_t tri;   // HVRT_MISS when nothing was hit
+    float t;
+    uint32_t nv, nt;
+};
+
+// traverseVoxelGrid, OctreeLikeRayTracer.cpp:309-336.
+__device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d) {
+    const GridParams& g = sc.g;
+    TraceResult r;
+    r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
+
+    // initializeTraversal, :155-195 (start voxel = CLAMPED voxel of the origin, no entry test)
+    int ix = clampi(f2i((o.x - g.mnx) / g.vsx), 0, g.nx - 1);
+    int iy = clampi(f2i((o.y - g.mny) / g.vsy), 0, g.ny - 1);
+    int iz = clampi(f2i((o.z - g.mnz) / g.vsz), 0, g.nz - 1);
+    const int sx = (d.x > 0.0f) ? 1 : -1, sy = (d.y > 0.0f) ? 1 : -1, sz = (d.z > 0.0f) ? 1 : -1;
+    const float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
+    float tmx = ((g.mnx + (float)((d.x > 0.0f) ? ix + 1 : ix) * g.vsx) - o.x) / d.x;
+    float tmy = ((g.mny + (float)((d.y > 0.0f) ? iy + 1 : iy) * g.vsy) - o.y) / d.y;
+    float tmz = ((g.mnz + (float)((d.z > 0.0f) ? iz + 1 : iz) * g.vsz) - o.z) / d.z;
+
+    const int max_steps = g.nx + g.ny + g.nz;   // :318
+    for (int it = 0; it < max_steps; ++it) {
+        if (!(ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz)) break;   // :321
+        // testVoxelTriangles, :267-295: the LAST list entry that hits wins
+        ++r.nv;
+        const uint64_t f = (uint64_t)ix + (uint64_t)g.nx * ((uint64_t)iy + (uint64_t)g.ny * (uint64_t)iz);
+        const uint32_t b0 = sc.offsets[f], b1 = sc.offsets[f + 1];
+        bool found = false;
+        for (uint32_t j = b0; j < b1; ++j) {
+            const uint32_t ti = sc.indices[j];
+            const float4 r0 = sc.tri_rec[3ull * ti], r1 = sc.tri_rec[3ull * ti + 1], r2 = sc.tri_rec[3ull * ti + 2];
+            float t;
+            ++r.nt;
+            if (ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, r2.x }, o, d, t)) {
+                r.tri = ti; r.t = t; found = true;
+            }
+        }
+        if (found) break;   // :326-329
+        // advanceToNextVoxel, :201-260 -- literal nested strict '<' (ties / NaN fall to the else arms)
+        if (tmx < tmy) {
+            if (tmx < tmz) { ix += sx; tmx += tdx; } else { iz += sz; tmz += tdz; }
+        } else {
+            if (tmy < tmz) { iy += sy; tmy += tdy; } else { iz += sz; tmz += tdz; }
+        }
+    }
+    return r;
+}
+
+// computeShading (OctreeLikeRayTracer.cpp:27-40) + LambertianShader (Shaders.cpp:4-22): with
+// r=g=b=kd=1 and inShadow=0 each channel is exactly 0.1f + max(0, N.L).
+__device__ __forceinline__ V3 shade(const SceneDev& sc, const TraceResult& r, V3 o, float v) {
+    if (r.tri != HVRT_MISS) {
+        const float4 r0 = sc.tri_rec[3ull * r.tri], r2 = sc.tri_rec[3ull * r.tri + 2];
+        V3 L = normalize(sub(o, { r0.x, r0.y, r0.z }));   // hit.point = triangle.v0 (:286)
+        V3 N = normalize({ r2.y, r2.z, r2.w });
+        float ndl = dot(N, L);
+        float k = (0.0f < ndl) ? ndl : 0.0f;
+        float c = 0.1f + k;
+        return { c, c, c };
+    }
+    return { 0.5f + 0.3f * v, 0.5f + 0.3f * v, 0.7f + 0.3f * v };
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x7feb352dU; h ^= h >> 15; h *= 0x846ca68bU; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ void jitter(uint32_t x, uint32_t y, uint32_t s, uint32_t seed, float& jx, float& jy) {
+    uint32_t h = mix32(x + 0x9E3779B9U * (y + 0x85EBCA6BU * (s + 0xC2B2AE35U * seed)));
+    uint32_t a = mix32(h ^ 0x68E31DA4U), b = mix32(h ^ 0xB5297A4DU);
+    jx = (float)(a >> 8) * (1.0f / 16777216.0f);
+    jy = (float)(b >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+    return v;
+}
+
+// Persistent threads: every wave loops pulling 8x8 pixel tiles until the queue is empty; the
+// exit condition (tile >= n_tiles) is reached by every wave whatever the grid size.
+__global__ __launch_bounds__(256) void k_render(SceneDev sc, RenderArgs ra) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
+    const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    const V3 org = { ra.frame.origin[0], ra.frame.origin[1], ra.frame.origin[2] };
+    const V3 ll = { ra.frame.lower_left[0], ra.frame.lower_left[1], ra.frame.lower_left[2] };
+    const V3 hor = { ra.frame.horizontal[0], ra.frame.horizontal[1], ra.frame.horizontal[2] };
+    const V3 ver = { ra.frame.vertical[0], ra.frame.vertical[1], ra.frame.vertical[2] };
+    uint64_t tot_nv = 0, tot_nt = 0;
+
+    for (;;) {
+        uint32_t tile = 0;
+        if (lane == 0) tile = atomicAdd(ra.tile_counter, 1u);
+        tile = __shfl(tile, 0);
+        if (tile >= n_tiles) break;
+        const uint32_t ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x = (int)(tx * 8u) + (lane & 7);
+        const int lr = (int)(ty * 8u) + (lane >> 3);
+        if (x >= ra.width || lr >= ra.local_rows) continue;
+        // local row -> global row: tile k of the image belongs to part k % n_parts
+        const int kl = lr / ra.tile_rows;
+        const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
+        if (y >= ra.height) continue;
+
+        V3 acc = { 0.0f, 0.0f, 0.0f };
+        uint32_t hit0 = HVRT_MISS; float t0 = FLT_MAX;
+        for (int s = 0; s < ra.spp; ++s) {
+            float jx = 0.0f, jy = 0.0f;
+            if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
+            // renderPixel, :73-74 (pixel corner; jitter is 0 at spp 1)
+            const float u = ((float)x + jx) / (float)ra.width;
+            const float v = ((float)y + jy) / (float)ra.height;
+            // generateRay, :361-364
+            const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
+            const TraceResult r = trace_ray(sc, org, d);
+            const V3 c = shade(sc, r, org, v);
+            if (ra.spp == 1) acc = c; else acc = add(acc, c);
+            if (s == 0) { hit0 = r.tri; t0 = r.t; }
+            tot_nv += r.nv; tot_nt += r.nt;
+        }
+        if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+        const size_t p = (size_t)lr * ra.width + x;
+        if (ra.rgb) { ra.rgb[3 * p] = acc.x; ra.rgb[3 * p + 1] = acc.y; ra.rgb[3 * p + 2] = acc.z; }
+        if (ra.hit_id) ra.hit_id[p] = hit0;
+        if (ra.t) ra.t[p] = t0;
+    }
+    if (ra.counters) {
+        tot_nv = wave_sum64(tot_nv);
+        tot_nt = wave_sum64(tot_nt);
+        if (lane == 0) {
+            atomicAdd(&ra.counters[0], (unsigned long long)tot_nv);
+            atomicAdd(&ra.counters[1], (unsigned long long)tot_nt);
+        }
+    }
+}
+
+// traceRay batch: one lane per ray, RayHit records out (OctreeLikeRayTracer.cpp:124-126, :283-288).
+__global__ __launch_bounds__(256) void k_trace(SceneDev sc, const float* __restrict__ origins,
+                                               const float* __restrict__ dirs, uint32_t n,
+                                               hvrt_hit* __restrict__ out, unsigned long long* counters) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint64_t nv = 0, nt = 0;
+    if (i < n) {
+        const V3 o = { origins[3ull * i], origins[3ull * i + 1], origins[3ull * i + 2] };
+        const V3 d = { dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2] };
+        const TraceResult r = trace_ray(sc, o, d);
+        hvrt_hit h;
+        h.hit = r.tri != HVRT_MISS;
+        h.t = r.t;
+        h.point[0] = h.point[1] = h.point[2] = 0.0f;
+        h.origin[0] = h.origin[1] = h.origin[2] = 0.0f;   // the reference leaves origin unset on a miss; we zero it
+        h.normal[0] = h.normal[1] = h.normal[2] = 0.0f;
+        h.triangle_index = 0;
+        h.voxel_index = 0;
+        if (h.hit) {
+            const float4 r0 = sc.tri_rec[3ull * r.tri], r2 = sc.tri_rec[3ull * r.tri + 2];
+            h.point[0] = r0.x; h.point[1] = r0.y; h.point[2] = r0.z;
+            h.origin[0] = o.x; h.origin[1] = o.y; h.origin[2] = o.z;
+            h.normal[0] = r2.y; h.normal[1] = r2.z; h.normal[2] = r2.w;
+            h.triangle_index = r.tri;
+        }
+        out[i] = h;
+        nv = r.nv; nt = r.nt;
+    }
+    if (counters) {
+        nv = wave_sum64(nv);
+        nt = wave_sum64(nt);
+        if ((threadIdx.x & 63) == 0 && (nv | nt)) {
+            atomicAdd(&counters[0], (unsigned long long)nv);
+            atomicAdd(&counters[1], (unsigned long long)nt);
+        }
+    }
+}
+
+// frame[y][x] <- parts[part(y)][local_row(y)][x], 4-byte words
+__global__ __launch_bounds__(256) void k_assemble(const uint32_t* __restrict__ parts, int words_per_row, int height,
+                                                  int tile_rows, int n_parts, int slab_rows,
+                                                  uint32_t* __restrict__ frame) {
+    const int y = blockIdx.y;
+    const int k = y / tile_rows;
+    const int part = k % n_parts;
+    const int lr = (k / n_parts) * tile_rows + (y - k * tile_rows);
+    const uint32_t* src = parts + ((size_t)part * slab_rows + lr) * words_per_row;
+    uint32_t* dst = frame + (size_t)y * words_per_row;
+    for (int w = blockIdx.x * 256 + threadIdx.x; w < words_per_row; w += gridDim.x * 256) dst[w] = src[w];
+    (void)height;
+}
+
+}  // namespace
+
+hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s) {
+    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3, tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+    const uint64_t n_tiles = (uint64_t)tiles_x * tiles_y;
+    if (n_tiles == 0) return hipSuccess;
+    uint64_t blocks = (n_tiles + 3) / 4;
+    const uint64_t cap = (uint64_t)n_cus * 8;   // 8 x 256-thread workgroups fill a CU's 32 wave slots
+    if (blocks > cap) blocks = cap;
+    k_render<<<(unsigned)blocks, 256, 0, s>>>(sc, ra);
+    return hipGetLastError();
+}
+
+hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n, hvrt_hit* out,
+                        unsigned long long* counters, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    k_trace<<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble(const void* parts, int width, int height, int tile_rows, int n_parts, int slab_rows,
+                           int bytes_per_pixel, void* frame, hipStream_t s) {
+    const int words = width * (bytes_per_pixel / 4);
+    if (words == 0 || height == 0) return hipSuccess;
+    int bx = (words + 255) / 256;
+    if (bx > 64) bx = 64;
+    k_assemble<<<dim3(bx, height), 256, 0, s>>>((const uint32_t*)parts, words, height, tile_rows, n_parts, slab_rows,
+                                                (uint32_t*)frame);
+    return hipGetLastError();
+}
+
+}  // namespace hvrt
