@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py -- primary-ray throughput at 4K on BASELINE.json config 2, plus voxel-grid build time.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+Workload (config.workload = "c2"): libm-free cube-sphere, 1 002 252 triangles, 256^3 grid, 3840x2160
+primary rays, the reference's front camera rule (TraceImages.cpp:125-146) with aspect = W/H, 1 spp,
+pixel-corner sampling.  A step = one pass of the hot path over one batch of rays:
+  N = 1 : the traversal kernel renders one 4K frame (rgb + hit id + t written) from the HBM-resident scene.
+  N > 1 : weak scaling -- a batch of N frames; every frame's 16-row tiles are interleaved over the N ranks,
+          each rank traces one frame's worth of rays per step, every frame is all-gathered with RCCL
+          (overlapped with the next frame's traversal) and reassembled.  value = all rays / max-over-ranks time.
+Output: ONE JSON line on rank 0 (metric / roofline / cpu_baseline as DESIGN.md section "Measurement" defines).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+WORKLOADS = {
+    # name: (cube-sphere n, grid, W, H)
+    "c2": (289, 256, 3840, 2160),
+    "small": (58, 50, 800, 600),          # config-1-shaped plumbing case (not a bench line)
+}
+
+
+def cpu_baseline(tris, g, mn, vs, off, idx, cam, W, H, n_rays_target=8.3e6):
+    """Times the oracle (our CPU port of the reference path, kind 'port') on a bounded sample of the SAME
+    frame: evenly spaced rows, all host threads of this box's CPU share."""
+    import oracle
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    sc = oracle.OracleScene(tris, g, g, g, mn, vs, off, idx)
+    n_rows = min(H, max(threads, int(n_rays_target // W)))
+    rows = np.linspace(0, H - 1, n_rows).astype(int)
+    from concurrent.futures import ThreadPoolExecutor
+    import ctypes as C
+    f = oracle.Frame.from_buffer_copy(bytes(cam))
+    cnts = [np.zeros(2, np.uint64) for _ in range(threads)]
+
+    def work(k):
+        for y in rows[k::threads]:
+            oracle.lib().orc_render_rows(C.byref(sc.c), C.byref(f), W, H, int(y), int(y) + 1, 1, C.c_uint32(0),
+                                         None, None, None, C.c_void_p(cnts[k].ctypes.data))
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work, range(threads)))
+    dt = time.perf_counter() - t0
+    rays = len(rows) * W
+    # voxel build on one core (flat CSR port of SceneCreator.cpp:197-281)
+    t1 = time.perf_counter()
+    oracle.voxelize(tris, g, g, g, mn, vs)
+    bt = time.perf_counter() - t1
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{len(rows)} evenly spaced rows of the same {W}x{H} frame ({rays} rays, {dt:.2f} s); "
+                      f"oracle/cpu_ref.c, one trace per pixel",
+            "build_ms_1core": bt * 1e3 / 2.0,   # voxelize() runs the count pass twice (sizing + fill)
+            }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as ra
+    from raytracer_amd import capi, meshgen
+    from raytracer_amd.distributed import DistributedRenderer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    n_sphere, g, W, H = WORKLOADS[args.workload]
+    ctx = ra.Context(local_rank)
+    dr = DistributedRenderer(ctx, rank, world, device, tile_rows=16)
+    tris = meshgen.cube_sphere(n_sphere) if rank == 0 else None
+    mn, mx, vs3 = dr.replicate_scene(tris, (g, g, g))
+    info = ctx.grid_info()
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
+    cam = capi.make_camera_frame(pos, la, up, fov, asp)
+
+    # ---- voxel-grid build time (rank 0's GPU; mesh resident in HBM) -------------------------------
+    build_ms = None
+    if rank == 0:
+        bt = []
+        for _ in range(5):
+            ctx.build_grid(g, g, g, mn, mx, vs3)
+            bt.append(ctx.timings().build_total_ms)
+        build_ms = float(np.median(bt))
+        tmb = ctx.timings()
+
+    # ---- per-ray work of this frame (V voxels, T triangle tests) from the kernel's own counters ----
+    rgb_d = torch.empty((H, W, 3), dtype=torch.float32, device=device)
+    hit_d = torch.empty((H, W), dtype=torch.int32, device=device)
+    t_d = torch.empty((H, W), dtype=torch.float32, device=device)
+    cnt_d = torch.zeros(2, dtype=torch.int64, device=device)
+    torch.cuda.synchronize(device)
+    ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), cnt_d.data_ptr())
+    ctx.synchronize()
+    V, T = (cnt_d.cpu().numpy() / float(W * H)).tolist()
+    hit_frac = float((hit_d != -1).float().mean().item())
+    bytes_per_ray = 8.0 * V + 40.0 * T + 12.0 + 8.0          # +8 because hit id and t are written
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        ctx.synchronize()
+
+    kernel_ms = []
+    if world == 1:
+        def step():
+            ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
+        rays_per_step = W * H
+    else:
+        dr.alloc(W, H, n_frames=world)
+        cams = [cam] * world
+
+        def step():
+            dr.render_frames(cams)
+        rays_per_step = W * H * world
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    if world == 1:
+        # per-launch kernel durations come from HIP events on libhvrt's own stream (hvrt_timings.render_ms);
+        # reading them needs the launch finished, so the launches are issued back to back and each is
+        # read after the stream drained -- the wall clock below brackets exactly K launches either way.
+        for _ in range(args.steps):
+            step()
+            ctx.synchronize()
+            kernel_ms.append(ctx.timings().render_ms)
+    else:
+        for _ in range(args.steps):
+            step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = rays_per_step / (ms_per_step * 1e-3) / 1e6
+        out = {
+            "metric": "primary Mrays/s (node) at 4K", "value": value, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "mesh": f"cube-sphere n={n_sphere}", "triangles": int(info.n_triangles),
+                       "grid": [g, g, g], "image": [W, H], "spp": 1, "camera": "reference front rule, aspect=W/H",
+                       "frames_per_step": world, "tile_rows": 16,
+                       "outputs": "rgb+hit_id+t" if world == 1 else "rgb, all_gather + reassemble"},
+            "voxel_build_ms": build_ms,
+            "voxel_build_breakdown_ms": {"count": tmb.build_count_ms, "scan": tmb.build_scan_ms,
+                                         "fill": tmb.build_fill_ms, "sort": tmb.build_sort_ms},
+            "scene": {"refs": int(info.n_refs), "occupied_voxels": int(info.n_occupied), "max_list": int(info.max_list),
+                      "voxels_per_ray": V, "tri_tests_per_ray": T, "hit_fraction": hit_frac},
+        }
+        if kernel_ms:
+            k_ms = float(np.mean(kernel_ms))
+            achieved = bytes_per_ray * W * H / (k_ms * 1e-3) / 1e9
+            traffic = None
+            tp = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tp):
+                try:
+                    traffic = json.load(open(tp)).get(args.workload, {}).get("k_render_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                               "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_render",
+                               "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
+                               "note": "algorithmic (requested) bytes 8V+40T+20 per ray; >1 means cache reuse"}
+            nvox = g ** 3
+            b_build = 72.0 * info.n_triangles + 12.0 * nvox + 20.0 * info.n_refs
+            out["roofline_build"] = {"bound": "hbm", "achieved": b_build / (build_ms * 1e-3) / 1e9, "peak": 8000.0,
+                                     "unit": "GB/s", "frac": b_build / (build_ms * 1e-3) / 1e9 / 8000.0,
+                                     "algorithmic_bytes": b_build}
+        if world == 1 and not args.no_cpu_baseline:
+            off, idx = ctx.get_csr()
+            if tris is None:
+                tris = meshgen.cube_sphere(n_sphere)
+            out["cpu_baseline"] = cpu_baseline(tris, g, mn, float(vs3[0]), off, idx, cam, W, H)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

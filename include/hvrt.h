@@ -95,6 +95,10 @@ const char* hvrt_last_error(const hvrt_ctx* ctx);
 /* The context's HIP stream as an opaque handle (hipStream_t), for callers that interleave their
  * own work (e.g. RCCL collectives) with hvrt calls. */
 void* hvrt_stream(hvrt_ctx* ctx);
+/* Issue all further work on the caller's HIP stream (e.g. the stream its RCCL collectives run on), so
+ * that renders and collectives order without host synchronisation.  NULL restores the context's own
+ * stream.  The stream must belong to the context's device and outlive its use here. */
+int hvrt_set_stream(hvrt_ctx* ctx, void* hip_stream);
 int hvrt_synchronize(hvrt_ctx* ctx);
 int hvrt_get_timings(const hvrt_ctx* ctx, hvrt_timings* out);
 
@@ -146,6 +150,13 @@ int hvrt_get_grid_info(const hvrt_ctx* ctx, hvrt_grid_info* out);
 int hvrt_get_csr(hvrt_ctx* ctx, uint32_t* offsets, uint32_t* indices);
 /* Device addresses of the resident arrays (for RCCL broadcast by the caller). */
 int hvrt_get_device_arrays(hvrt_ctx* ctx, void** d_tri_aos, void** d_offsets, void** d_indices);
+
+/* Copies the resident scene into caller-provided device buffers (each nullable): n_tris*48 bytes,
+ * (n_voxels+1)*4 bytes, n_refs*4 bytes.  This is the send side of the multi-GPU scene replication
+ * (the caller broadcasts the buffers with RCCL; receivers call hvrt_set_mesh_device and
+ * hvrt_set_grid_csr_device).  No reference counterpart: the reference is single-process.
+ * Asynchronous on the context's stream. */
+int hvrt_export_scene_device(hvrt_ctx* ctx, void* d_tri_aos, void* d_offsets, void* d_indices);
 
 /* ---- rendering ----------------------------------------------------------------------------- */
 

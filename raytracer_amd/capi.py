@@ -20,10 +20,10 @@ HVRT_MISS = 0xFFFFFFFF
 
 # every symbol include/hvrt.h declares (tests check the library exports each of them)
 SYMBOLS = [
-    "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_synchronize", "hvrt_get_timings",
+    "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_set_stream", "hvrt_synchronize", "hvrt_get_timings",
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
-    "hvrt_get_device_arrays", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device",
+    "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace",
 ]
 
@@ -67,6 +67,13 @@ def load_library() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise HvrtError(-100, f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
                               "(or __graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.  If torch is going to be
+    # used in this process (tests, bench, RCCL driver) it must be the first to load the runtime, or
+    # torch later finds "No HIP GPUs"; libhvrt then binds to the copy already mapped.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, f3 = C.c_void_p, C.POINTER(C.c_float)
     lib.hvrt_create.argtypes = [C.POINTER(vp), C.c_int]
@@ -76,6 +83,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_last_error.restype = C.c_char_p
     lib.hvrt_stream.argtypes = [vp]
     lib.hvrt_stream.restype = vp
+    lib.hvrt_set_stream.argtypes = [vp, vp]
     lib.hvrt_synchronize.argtypes = [vp]
     lib.hvrt_get_timings.argtypes = [vp, C.POINTER(Timings)]
     lib.hvrt_set_mesh.argtypes = [vp, vp, C.c_uint32]
@@ -90,6 +98,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_get_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
     lib.hvrt_get_csr.argtypes = [vp, vp, vp]
     lib.hvrt_get_device_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.hvrt_export_scene_device.argtypes = [vp, vp, vp, vp]
     lib.hvrt_make_camera_frame.argtypes = [f3, f3, f3, C.c_float, C.c_float, C.POINTER(CameraFrame)]
     lib.hvrt_make_camera_frame.restype = None
     lib.hvrt_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp]
@@ -248,6 +257,10 @@ class Context:
         self._ck(self._lib.hvrt_get_device_arrays(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def export_scene_device(self, d_tri_aos: int = 0, d_offsets: int = 0, d_indices: int = 0):
+        vp = lambda p: C.c_void_p(p) if p else None
+        self._ck(self._lib.hvrt_export_scene_device(self._h, vp(d_tri_aos), vp(d_offsets), vp(d_indices)))
+
     def timings(self) -> Timings:
         t = Timings()
         self._ck(self._lib.hvrt_get_timings(self._h, C.byref(t)))
@@ -255,6 +268,9 @@ class Context:
 
     def synchronize(self):
         self._ck(self._lib.hvrt_synchronize(self._h))
+
+    def set_stream(self, hip_stream: int | None):
+        self._ck(self._lib.hvrt_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     @property
     def stream(self) -> int:

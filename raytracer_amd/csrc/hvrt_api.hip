@@ -17,7 +17,8 @@ using namespace hvrt;
 struct hvrt_ctx {
     int device = 0;
     int n_cus = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // the stream all work is issued on (own_stream unless hvrt_set_stream)
+    hipStream_t own_stream = nullptr;
     hipEvent_t ev[8] = {};
     std::string error;
 
@@ -169,7 +170,8 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     hipDeviceProp_t prop;
     if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess) return bail("hipGetDeviceProperties", e);
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    c->stream = c->own_stream;
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&c->stats, 8 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
@@ -185,19 +187,27 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
 void hvrt_destroy(hvrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ranges, c->block_sums, c->stats, c->long_queue,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
 
 const char* hvrt_last_error(const hvrt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
 
 void* hvrt_stream(hvrt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int hvrt_set_stream(hvrt_ctx* c, void* hip_stream) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // nothing of ours may still run on the old stream
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return HVRT_OK;
+}
 
 int hvrt_synchronize(hvrt_ctx* c) {
     if (!c) return HVRT_ERR_INVALID;
@@ -409,6 +419,19 @@ int hvrt_get_device_arrays(hvrt_ctx* c, void** d_tri_aos, void** d_offsets, void
     if (d_tri_aos) *d_tri_aos = c->tri_aos;
     if (d_offsets) *d_offsets = c->has_grid ? (void*)offsets_of(c) : nullptr;
     if (d_indices) *d_indices = c->has_grid ? (void*)c->indices : nullptr;
+    return HVRT_OK;
+}
+
+int hvrt_export_scene_device(hvrt_ctx* c, void* d_tri_aos, void* d_offsets, void* d_indices) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (d_tri_aos && c->n_tris)
+        HIP_TRY(c, hipMemcpyAsync(d_tri_aos, c->tri_aos, (size_t)c->n_tris * 48, hipMemcpyDeviceToDevice, c->stream));
+    if ((d_offsets || d_indices) && !c->has_grid) return fail(c, HVRT_ERR_INVALID, "export_scene: no grid");
+    if (d_offsets)
+        HIP_TRY(c, hipMemcpyAsync(d_offsets, offsets_of(c), (c->g.nvox + 1) * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (d_indices && c->n_refs)
+        HIP_TRY(c, hipMemcpyAsync(d_indices, c->indices, c->n_refs * 4, hipMemcpyDeviceToDevice, c->stream));
     return HVRT_OK;
 }
 

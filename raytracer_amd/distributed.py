@@ -1,0 +1,140 @@
+"""Multi-GPU rendering: one process per GPU over torch.distributed (backend "nccl" == RCCL on ROCm).
+
+The path shards by image row tiles with no exchange during compute:
+  * the scene (triangles + CSR grid) is REPLICATED: built on rank 0, broadcast with RCCL, ingested by
+    the other ranks through hvrt_set_mesh_device / hvrt_set_grid_csr_device;
+  * row tile k of a frame belongs to rank k % world (interleaved: silhouette rows cost far more than
+    background rows), each rank renders its tiles into a compact slab;
+  * ONE collective per frame gathers the slabs (all_gather of equal, padded slabs over xGMI) and a
+    de-interleave kernel (hvrt_assemble_parts_device) rebuilds the frame.  There is no reduction, so an
+    N-GPU frame is bytewise the 1-GPU frame.
+
+torch is plumbing here (device buffers, streams, the process group); every kernel is libhvrt's.
+The collective helpers are device-agnostic so that the choreography is testable on CPU with gloo.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+@dataclass
+class Partition:
+    """Row-tile partition of an H-row frame over `world` parts (host arithmetic only)."""
+    height: int
+    tile_rows: int
+    world: int
+
+    def rows_of(self, part: int) -> int:
+        n_tiles = -(-self.height // self.tile_rows)
+        return sum(min(self.tile_rows, self.height - k * self.tile_rows) for k in range(part, n_tiles, self.world))
+
+    @property
+    def slab_rows(self) -> int:
+        return max(self.rows_of(p) for p in range(self.world))
+
+    def global_rows(self, part: int) -> np.ndarray:
+        """Global row index of every local row of `part`, in slab order."""
+        n_tiles = -(-self.height // self.tile_rows)
+        out = []
+        for k in range(part, n_tiles, self.world):
+            out.extend(range(k * self.tile_rows, min((k + 1) * self.tile_rows, self.height)))
+        return np.asarray(out, np.int64)
+
+
+def gather_parts(local_slab: torch.Tensor, group=None) -> torch.Tensor:
+    """all_gather of equal-shaped slabs -> [world, *slab.shape] on every rank (RCCL on GPUs, gloo on CPU)."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world,) + tuple(local_slab.shape), dtype=local_slab.dtype, device=local_slab.device)
+    if world == 1:
+        out[0].copy_(local_slab)
+        return out
+    try:
+        dist.all_gather_into_tensor(out, local_slab.contiguous(), group=group)
+    except (RuntimeError, NotImplementedError):      # gloo builds without the fused form
+        dist.all_gather(list(out.unbind(0)), local_slab.contiguous(), group=group)
+    return out
+
+
+def broadcast_arrays(tensors, src: int = 0, group=None):
+    for t in tensors:
+        dist.broadcast(t, src=src, group=group)
+
+
+class DistributedRenderer:
+    """Replicated-scene, row-tile-partitioned renderer for one rank (one GPU)."""
+
+    def __init__(self, ctx: capi.Context, rank: int, world: int, device: torch.device, tile_rows: int = 16):
+        self.ctx, self.rank, self.world, self.device, self.tile_rows = ctx, rank, world, device, tile_rows
+        # run libhvrt on a stream torch knows, so renders and collectives order through events
+        self.stream = torch.cuda.ExternalStream(ctx.stream, device=device)
+
+    # ---- scene replication -------------------------------------------------------------------
+    def replicate_scene(self, tri_aos: np.ndarray | None, dims, src: int = 0):
+        """Rank `src` holds tri_aos (others pass None).  Builds the grid on src, broadcasts mesh + CSR."""
+        nx, ny, nz = dims
+        meta = torch.zeros(16, dtype=torch.float64, device=self.device)
+        if self.rank == src:
+            self.ctx.set_mesh(tri_aos)
+            mn, mx = self.ctx.mesh_bounds()
+            vs = capi.voxel_size(mn, mx, nx, ny, nz)
+            info = self.ctx.build_grid(nx, ny, nz, mn, mx, vs)
+            meta[:9] = torch.tensor(list(mn) + list(mx) + [float(vs)] * 3, dtype=torch.float64)
+            meta[9], meta[10] = float(info.n_triangles), float(info.n_refs)
+        if self.world > 1:
+            dist.broadcast(meta, src=src)
+        m = meta.cpu().numpy()
+        mn, mx, vs3 = m[:3].astype(np.float32), m[3:6].astype(np.float32), m[6:9].astype(np.float32)
+        n_tris, n_refs = int(m[9]), int(m[10])
+        if self.world > 1:
+            tri = torch.empty(max(n_tris, 1) * 12, dtype=torch.float32, device=self.device)
+            off = torch.empty(nx * ny * nz + 1, dtype=torch.int32, device=self.device)
+            idx = torch.empty(max(n_refs, 1), dtype=torch.int32, device=self.device)
+            if self.rank == src:
+                self.ctx.export_scene_device(tri.data_ptr(), off.data_ptr(), idx.data_ptr())
+                self.ctx.synchronize()
+            torch.cuda.synchronize(self.device)
+            broadcast_arrays([tri, off, idx], src=src)
+            torch.cuda.synchronize(self.device)
+            if self.rank != src:
+                self.ctx.set_mesh_device(tri.data_ptr(), n_tris)
+                self.ctx.set_grid_csr_device(nx, ny, nz, mn, mx, vs3, off.data_ptr(), idx.data_ptr(), n_refs)
+        return mn, mx, vs3
+
+    # ---- frames --------------------------------------------------------------------------------
+    def alloc(self, width: int, height: int, n_frames: int = 1):
+        part = Partition(height, self.tile_rows, self.world)
+        self.part = part
+        self.local = torch.zeros((n_frames, part.slab_rows, width, 3), dtype=torch.float32, device=self.device)
+        self.gathered = [torch.empty((self.world, part.slab_rows, width, 3), dtype=torch.float32, device=self.device)
+                         for _ in range(n_frames)]
+        self.frames = torch.empty((n_frames, height, width, 3), dtype=torch.float32, device=self.device)
+        self.width, self.height = width, height
+
+    def render_frames(self, cam_frames, spp: int = 1, seed: int = 0):
+        """Renders this rank's tiles of every frame, gathers each frame as soon as it is rendered (the
+        next frame's traversal overlaps the previous frame's all_gather), reassembles on every rank."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        for f, cam in enumerate(cam_frames):
+            self.ctx.render_part_device(cam, self.width, self.height, spp, seed, self.tile_rows, self.rank,
+                                        self.world, d_rgb=self.local[f].data_ptr())
+            if self.world == 1:
+                continue
+            ev = self.stream.record_event()
+            cur.wait_event(ev)
+            dist.all_gather_into_tensor(self.gathered[f], self.local[f])
+        if self.world == 1:
+            cur.wait_stream(self.stream)
+            return self.local[:, :self.height]          # one part: the slab is the frame
+        self.stream.wait_stream(cur)
+        for f in range(len(cam_frames)):
+            self.ctx.assemble_parts_device(self.gathered[f].data_ptr(), self.width, self.height, self.tile_rows,
+                                           self.world, self.part.slab_rows, 12, self.frames[f].data_ptr())
+        cur.wait_stream(self.stream)
+        return self.frames

@@ -1,0 +1,169 @@
+"""GPU parity: voxel-grid build through the C ABI vs the oracle -- bit-exact CSR (offsets + indices)."""
+import numpy as np
+import pytest
+
+import oracle
+from raytracer_amd import capi, meshgen
+
+pytestmark = pytest.mark.gpu
+
+
+def build_both(ctx, tris, dims, points=None):
+    nx, ny, nz = dims
+    ctx.set_mesh(tris)
+    pts = tris[:, :9].reshape(-1, 3) if points is None else points
+    mn, mx = ctx.compute_bounds(pts) if points is not None else ctx.mesh_bounds()
+    omn, omx = oracle.mesh_bounds(pts)
+    assert np.array_equal(mn.view(np.uint32), omn.view(np.uint32))
+    assert np.array_equal(mx.view(np.uint32), omx.view(np.uint32))
+    vs = capi.voxel_size(mn, mx, nx, ny, nz)
+    info = ctx.build_grid(nx, ny, nz, mn, mx, vs)
+    off, idx = ctx.get_csr()
+    ooff, oidx = oracle.voxelize(tris, nx, ny, nz, mn, vs)
+    assert np.array_equal(off, ooff), "CSR offsets differ"
+    assert np.array_equal(idx, oidx), "CSR indices differ"
+    cnt = np.diff(ooff.astype(np.int64))
+    assert info.n_refs == oidx.size and info.n_occupied == int((cnt > 0).sum())
+    assert info.max_list == (int(cnt.max()) if cnt.size else 0)
+    return info, off, idx, mn, mx, vs
+
+
+FIXTURES = {
+    "cube_on_voxel_planes": lambda: (meshgen.box(), (8, 8, 8)),
+    "sphere_16": lambda: (meshgen.cube_sphere(12), (16, 16, 16)),
+    "sphere_32": lambda: (meshgen.cube_sphere(24), (32, 32, 32)),
+    "sphere_50": lambda: (meshgen.cube_sphere(58), (50, 50, 50)),
+    "offcentre_noncubic": lambda: (meshgen.cube_sphere(20, 0.7, center=(3.0, -2.0, 11.5)) *
+                                   np.array([1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], np.float32), (40, 13, 27)),
+    "offcentre_box_overhang": lambda: (meshgen.box((1.0, 2.0, 3.0), (4.0, 2.5, 3.25)), (20, 20, 20)),
+    "slivers": lambda: (meshgen.slivers(400, 5), (32, 32, 32)),
+    "random_soup": lambda: (meshgen.random_soup(5000, 11), (33, 17, 29)),
+    "one_triangle": lambda: (meshgen.to_aos(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0.5]]], np.float32)), (5, 5, 5)),
+    "single_voxel_grid": lambda: (meshgen.cube_sphere(6), (1, 1, 1)),
+    "flat_grid": lambda: (meshgen.cube_sphere(10), (64, 64, 1)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_csr_bit_exact(ctx, name):
+    tris, dims = FIXTURES[name]()
+    build_both(ctx, np.ascontiguousarray(tris, np.float32), dims)
+
+
+def test_long_lists_all_sort_tiers(ctx):
+    """Lists of > 32 (LDS bitonic), > 4096 (128 KiB LDS) and > 32768 (global-memory bitonic) entries."""
+    tris = meshgen.skewed_statue(12, 300)           # 180 000 patch triangles under a handful of voxels
+    info, *_ = build_both(ctx, tris, (8, 8, 8))
+    assert info.max_list > 32768
+    info, *_ = build_both(ctx, tris, (24, 24, 24))
+    assert 4096 < info.max_list <= 32768
+    info, *_ = build_both(ctx, meshgen.skewed_statue(30, 60), (32, 32, 32))
+    assert 32 < info.max_list <= 4096
+
+
+def test_big_triangles_take_the_wave_cooperative_path(ctx):
+    """Two triangles spanning a whole slab of the grid (range volume >> 32 voxels) among small ones."""
+    big = np.array([[[-1, -1, 0.013], [1, -1, 0.013], [1, 1, 0.013]],
+                    [[-1, -1, -0.4], [1, 1, 0.9], [-1, 1, -0.4]]], np.float32)
+    tris = np.concatenate([meshgen.cube_sphere(10), meshgen.to_aos(big), meshgen.random_soup(700, 2, size=0.6)])
+    build_both(ctx, tris, (48, 48, 48))
+
+
+def test_empty_and_degenerate_inputs(ctx):
+    # no triangles at all: every voxel empty
+    ctx.set_mesh(np.zeros((0, 12), np.float32))
+    one = np.ones(3, np.float32)
+    info = ctx.build_grid(4, 4, 4, -one, one, 0.5)
+    off, idx = ctx.get_csr()
+    assert info.n_refs == 0 and idx.size == 0 and not off.any() and off.size == 65
+    # a mesh that is a single point: voxel size 0 -> 0/0 = NaN -> index 0 (cvttss2si + clamp), as the reference
+    pt = meshgen.to_aos(np.full((3, 3, 3), 2.5, np.float32))
+    build_both(ctx, pt, (4, 4, 4))
+    # NaN / inf corners
+    t = meshgen.random_soup(200, 9)
+    t[3, 0] = np.nan
+    t[17, 4] = np.inf
+    t[40, 8] = -np.inf
+    t[77, :9] = np.nan
+    ctx.set_mesh(t)
+    mn, mx = ctx.mesh_bounds()
+    omn, omx = oracle.mesh_bounds(t[:, :9].reshape(-1, 3))
+    assert np.array_equal(mn.view(np.uint32), omn.view(np.uint32)) and np.array_equal(mx.view(np.uint32), omx.view(np.uint32))
+    vs = capi.voxel_size(mn, mx, 16, 16, 16)
+    ctx.build_grid(16, 16, 16, mn, mx, vs)
+    off, idx = ctx.get_csr()
+    ooff, oidx = oracle.voxelize(t, 16, 16, 16, mn, vs)
+    assert np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
+def test_bounds_signed_zero_first_occurrence_wins(ctx):
+    """std::min keeps the first of +0 / -0 (SceneCreator.cpp:71-76); the GPU reduction must as well."""
+    pts = np.ones((100000, 3), np.float32)
+    pts[70000] = [-0.0, 0.0, -0.0]
+    pts[70001] = [0.0, -0.0, 0.0]
+    pts[5] = [3.0, 3.0, 3.0]
+    pts[99999] = [3.0, 3.0, 3.0]
+    pts[12345] = [np.nan, np.inf, -np.inf]
+    mn, mx = ctx.compute_bounds(pts)
+    omn, omx = oracle.mesh_bounds(pts)
+    assert np.array_equal(mn.view(np.uint32), omn.view(np.uint32))
+    assert np.array_equal(mx.view(np.uint32), omx.view(np.uint32))
+    assert np.signbit(mn[0]) and not np.signbit(mn[1]) and np.signbit(mn[2])
+
+
+def test_build_is_deterministic(ctx):
+    tris = meshgen.skewed_statue(20, 120)
+    ctx.set_mesh(tris)
+    mn, mx = ctx.mesh_bounds()
+    vs = capi.voxel_size(mn, mx, 40, 40, 40)
+    first = None
+    for _ in range(10):
+        ctx.build_grid(40, 40, 40, mn, mx, vs)
+        off, idx = ctx.get_csr()
+        if first is None:
+            first = (off, idx)
+        assert np.array_equal(off, first[0]) and np.array_equal(idx, first[1])
+
+
+def test_ingest_cpu_built_csr_round_trip(ctx):
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx, vs = oracle.build_scene(tris, 20, 20, 20)
+    ctx.set_mesh(tris)
+    ctx.set_grid_csr(20, 20, 20, mn, mx, vs, sc.offsets, sc.indices)
+    off, idx = ctx.get_csr()
+    assert np.array_equal(off, sc.offsets) and np.array_equal(idx, sc.indices)
+    info = ctx.grid_info()
+    cnt = np.diff(sc.offsets.astype(np.int64))
+    assert info.n_occupied == int((cnt > 0).sum()) and info.max_list == int(cnt.max())
+
+
+def test_errors_are_reported_not_swallowed(ctx):
+    one = np.ones(3, np.float32)
+    ctx.set_mesh(meshgen.box())
+    with pytest.raises(capi.HvrtError):
+        ctx.build_grid(0, 4, 4, -one, one, 0.5)
+    with pytest.raises(capi.HvrtError):
+        ctx.build_grid(70000, 1, 1, -one, one, 0.5)
+    with pytest.raises(capi.HvrtError):
+        ctx.grid_info()          # the failed build left no grid behind
+    ctx.build_grid(4, 4, 4, -one, one, 0.5)
+    assert ctx.grid_info().n_refs > 0
+
+
+def test_config2_full_size_csr(ctx):
+    """BASELINE config 2: 1 002 252-triangle sphere into 256^3 -- full bit-exact compare plus the
+    size-independent properties (monotone offsets, ascending lists, per-triangle reference count)."""
+    tris = meshgen.cube_sphere(289)
+    assert tris.shape[0] == 1002252
+    info, off, idx, mn, mx, vs = build_both(ctx, tris, (256, 256, 256))
+    assert (np.diff(off.astype(np.int64)) >= 0).all() and off[0] == 0 and off[-1] == idx.size
+    # ascending inside every list: a descent may only happen at a list boundary
+    desc = np.flatnonzero(np.diff(idx.astype(np.int64)) <= 0) + 1
+    assert np.isin(desc, off).all()
+    # every triangle is referenced exactly vol(range) times
+    refs = np.bincount(idx, minlength=tris.shape[0])
+    t = tris[:, :9].reshape(-1, 3, 3)
+    f = np.float32
+    lo = np.clip(((t.min(1) - mn).astype(f) / f(vs)).astype(np.int32), 0, 255)
+    hi = np.clip(((t.max(1) - mn).astype(f) / f(vs)).astype(np.int32), 0, 255)
+    assert np.array_equal(refs, np.prod(hi - lo + 1, axis=1))

@@ -1,0 +1,214 @@
+"""GPU parity: primary-ray traversal / shading through the C ABI vs the oracle.
+
+The bar (north_star): hit ids equal on >= 99.99 % of pixels, t / normals within 1e-5 relative.  What is
+asserted here is stricter -- hit ids, t, colours and the voxel / triangle-test counters are all
+BIT-EXACT -- because the kernels keep the reference's fp32 operation order (no FMA contraction) and its
+NaN / inf control flow."""
+import numpy as np
+import pytest
+
+import oracle
+from raytracer_amd import capi, meshgen
+
+pytestmark = pytest.mark.gpu
+MISS = 0xFFFFFFFF
+
+
+def setup_scene(ctx, tris, dims):
+    sc, mn, mx, vs = oracle.build_scene(tris, *dims)
+    ctx.set_mesh(tris)
+    ctx.build_grid(*dims, mn, mx, vs)
+    return sc, mn, mx
+
+
+def assert_frames_equal(got, exp):
+    rgb, hit, t, cnt = got
+    orgb, ohit, ot, ocnt = exp
+    n = hit.size
+    same = int((hit == ohit).sum())
+    assert same >= n * 0.9999, f"hit ids equal on only {same}/{n}"
+    assert np.array_equal(hit, ohit)
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32))
+    if cnt is not None:
+        assert np.array_equal(cnt, ocnt)
+    # the tolerance the metric states, spelled out (trivially true once bits agree)
+    m = ohit != MISS
+    assert np.all(np.abs(t[m] - ot[m]) <= 1e-5 * np.abs(ot[m]))
+
+
+SCENES = {
+    "cube_on_voxel_planes": (lambda: meshgen.box(), (8, 8, 8), (160, 120)),
+    "sphere_16": (lambda: meshgen.cube_sphere(12), (16, 16, 16), (200, 150)),
+    "sphere_50_default_res": (lambda: meshgen.cube_sphere(58), (50, 50, 50), (800, 600)),   # config 1 shape
+    "offcentre_noncubic": (lambda: meshgen.cube_sphere(20, 0.7, center=(3.0, -2.0, 11.5)), (40, 13, 27), (240, 180)),
+    "slivers": (lambda: meshgen.slivers(400, 5), (32, 32, 32), (320, 240)),
+    "skewed_long_lists": (lambda: meshgen.skewed_statue(30, 120), (32, 32, 32), (320, 240)),
+    "random_soup": (lambda: meshgen.random_soup(3000, 4), (33, 17, 29), (256, 192)),
+}
+
+
+@pytest.mark.parametrize("view", ["front", "side", "top"])
+@pytest.mark.parametrize("name", sorted(SCENES))
+def test_render_bit_exact(ctx, name, view):
+    """FRONT / SIDE / TOP cameras of TraceImageMultiView (TraceImages.cpp:148-197).  Centred meshes make
+    dir components exactly zero on the middle row / column: the inf / NaN tMax paths."""
+    gen, dims, (W, H) = SCENES[name]
+    tris = gen()
+    sc, mn, mx = setup_scene(ctx, tris, dims)
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, view)
+    fr = capi.make_camera_frame(pos, la, up, fov, asp)
+    got = ctx.render(fr, W, H)
+    exp = sc.render(fr, W, H, threads=8)
+    assert_frames_equal(got, exp)
+    if name.startswith("sphere") and view == "front":
+        hit = got[1]
+        assert (hit != MISS).any()
+        # F7: on the middle row (dir.y == 0 exactly) rays miss inside the silhouette
+        mid = hit[H // 2]
+        above = hit[H // 2 + 1]
+        assert (mid == MISS).sum() > (above == MISS).sum()
+
+
+def test_odd_sizes_and_tiny_images(ctx):
+    tris = meshgen.cube_sphere(12)
+    sc, mn, mx = setup_scene(ctx, tris, (16, 16, 16))
+    pos, la, up, fov, asp = capi.default_camera(mn, mx)
+    fr = capi.make_camera_frame(pos, la, up, fov, asp)
+    for (W, H) in [(1, 1), (3, 5), (9, 7), (63, 65), (130, 17)]:
+        assert_frames_equal(ctx.render(fr, W, H), sc.render(fr, W, H, threads=1))
+
+
+def test_camera_inside_and_far_away(ctx):
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx = setup_scene(ctx, tris, (24, 24, 24))
+    for pos, la in [((0.1, 0.05, 0.2), (1, 0.3, 0.2)),        # origin inside the grid
+                    ((0, 0, -1e6), (0, 0, 0)),                # very far: huge tMax values
+                    ((40, 30, -20), (0, 0, 0)),               # oblique, start voxel clamped on 3 axes
+                    ((0.5, 0.5, 0.5), (0.5, 0.5, 5))]:
+        fr = capi.make_camera_frame(pos, la, (0, 1, 0), 60.0, 4 / 3)
+        assert_frames_equal(ctx.render(fr, 160, 120), sc.render(fr, 160, 120, threads=4))
+
+
+def test_trace_ray_batch(ctx):
+    """IRayTracer::traceRay semantics incl. axis-parallel rays, zero directions, NaN, origins inside."""
+    tris = meshgen.cube_sphere(20)
+    sc, mn, mx = setup_scene(ctx, tris, (32, 32, 32))
+    rng = np.random.default_rng(5)
+    n = 4000
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    aim = rng.random(n) < 0.6                                   # aim most rays at the sphere
+    tgt = rng.normal(size=(n, 3)) * 0.4
+    dd = tgt - o
+    dd = (dd / np.linalg.norm(dd, axis=1, keepdims=True)).astype(np.float32)
+    d[aim] = dd[aim]
+    o[:200] = rng.uniform(-0.9, 0.9, (200, 3))                  # origins inside the grid
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0],
+                     [-0.0, 0.0, 1.0], [np.nan, 0, 1], [0, np.inf, 0], [1, 1, 0]], np.float32)
+    k = 200
+    for a in axes:
+        d[k:k + 20] = a
+        k += 20
+    o[k:k + 20] = np.float32(-1.0)                               # exactly on the grid's min corner
+    got, gcnt = ctx.trace(o, d)
+    exp, ecnt = sc.trace(o, d)
+    assert np.array_equal(gcnt, ecnt)
+    for f in ("hit", "triangle_index", "voxel_index"):
+        assert np.array_equal(got[f], exp[f]), f
+    for f in ("t", "point", "origin", "normal"):
+        assert np.array_equal(got[f].view(np.uint32), exp[f].view(np.uint32)), f
+    assert 0 < got["hit"].sum() < n
+    miss = got["hit"] == 0
+    assert np.all(got["t"][miss] == np.finfo(np.float32).max) and np.all(got["triangle_index"][miss] == 0)
+
+
+def test_jittered_supersampling_extension(ctx):
+    """spp > 1 (config 4's mode): no reference counterpart -- pinned by the oracle only."""
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx = setup_scene(ctx, tris, (24, 24, 24))
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, aspect=16 / 9)
+    fr = capi.make_camera_frame(pos, la, up, fov, asp)
+    for spp, seed in [(4, 1), (16, 1234)]:
+        got = ctx.render(fr, 192, 108, spp=spp, seed=seed)
+        exp = sc.render(fr, 192, 108, spp=spp, seed=seed, threads=8)
+        assert_frames_equal(got, exp)
+    a = ctx.render(fr, 192, 108, spp=4, seed=1)[0]
+    b = ctx.render(fr, 192, 108, spp=4, seed=2)[0]
+    assert not np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("n_parts,tile_rows", [(2, 16), (3, 8), (8, 16), (4, 37), (8, 1)])
+def test_row_tile_partition_reassembles_to_the_single_gpu_frame(ctx, n_parts, tile_rows):
+    """The multi-GPU partition on one GPU: render every part into its slab, reassemble, compare bytewise
+    with the one-part frame (no reduction anywhere => exact equality is the right assertion)."""
+    import torch
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx = setup_scene(ctx, tris, (24, 24, 24))
+    W, H = 200, 150
+    pos, la, up, fov, asp = capi.default_camera(mn, mx)
+    fr = capi.make_camera_frame(pos, la, up, fov, asp)
+    full_rgb, full_hit, full_t, _ = ctx.render(fr, W, H)
+    slab = max(capi.part_rows(H, tile_rows, p, n_parts) for p in range(n_parts))
+    dev = torch.device("cuda:0")
+    parts_rgb = torch.zeros((n_parts, slab, W, 3), dtype=torch.float32, device=dev)
+    parts_hit = torch.zeros((n_parts, slab, W), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for p in range(n_parts):
+        ctx.render_part_device(fr, W, H, 1, 0, tile_rows, p, n_parts,
+                               d_rgb=parts_rgb[p].data_ptr(), d_hit=parts_hit[p].data_ptr())
+    out_rgb = torch.empty((H, W, 3), dtype=torch.float32, device=dev)
+    out_hit = torch.empty((H, W), dtype=torch.int32, device=dev)
+    ctx.assemble_parts_device(parts_rgb.data_ptr(), W, H, tile_rows, n_parts, slab, 12, out_rgb.data_ptr())
+    ctx.assemble_parts_device(parts_hit.data_ptr(), W, H, tile_rows, n_parts, slab, 4, out_hit.data_ptr())
+    ctx.synchronize()
+    assert np.array_equal(out_rgb.cpu().numpy().view(np.uint32), full_rgb.view(np.uint32))
+    assert np.array_equal(out_hit.cpu().numpy().view(np.uint32), full_hit)
+
+
+def test_render_requires_a_scene(ctx):
+    ctx.set_mesh(meshgen.box())      # drops any grid
+    fr = capi.make_camera_frame((0, 0, -5), (0, 0, 0), (0, 1, 0), 60.0, 4 / 3)
+    with pytest.raises(capi.HvrtError):
+        ctx.render(fr, 16, 16)
+
+
+def test_config2_full_size_render_rows(ctx):
+    """BASELINE config 2 at full size (1 002 252 triangles, 256^3, 3840x2160): every 8th row compared
+    bit-for-bit with the oracle; all rows checked against frame-level properties."""
+    tris = meshgen.cube_sphere(289)
+    ctx.set_mesh(tris)
+    mn, mx = ctx.mesh_bounds()
+    vs = capi.voxel_size(mn, mx, 256, 256, 256)
+    ctx.build_grid(256, 256, 256, mn, mx, vs)
+    off, idx = ctx.get_csr()
+    sc = oracle.OracleScene(tris, 256, 256, 256, mn, vs, off, idx)   # CSR itself is checked in test_gpu_build
+    W, H = 3840, 2160
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, aspect=W / H)
+    fr = capi.make_camera_frame(pos, la, up, fov, asp)
+    rgb, hit, t, cnt = ctx.render(fr, W, H)
+    rows = list(range(0, H, 8))
+    ohit = np.zeros((len(rows), W), np.uint32)
+    ot = np.zeros((len(rows), W), np.float32)
+    orgb = np.zeros((len(rows), W, 3), np.float32)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def band(k):
+        r = sc.render(fr, W, H, threads=1, rows=(rows[k], rows[k] + 1))
+        orgb[k], ohit[k], ot[k] = r[0][rows[k]], r[1][rows[k]], r[2][rows[k]]
+
+    with ThreadPoolExecutor(16) as ex:
+        list(ex.map(band, range(len(rows))))
+    assert np.array_equal(hit[rows], ohit)
+    assert np.array_equal(t[rows].view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(rgb[rows].view(np.uint32), orgb.view(np.uint32))
+    # properties over the whole frame
+    m = hit != MISS
+    assert 0.03 < m.mean() < 0.10
+    assert hit[m].max() < tris.shape[0]
+    assert np.all(t[~m] == np.finfo(np.float32).max) and np.all(t[m] > 0) and np.all(np.isfinite(t[m]))
+    assert np.all((rgb[m] >= 0.1) & (rgb[m] <= 1.1001))
+    v = (np.arange(H, dtype=np.float32) / np.float32(H))[:, None]
+    bg = np.float32(0.5) + np.float32(0.3) * v
+    assert np.array_equal(np.broadcast_to(bg, (H, W))[~m], rgb[..., 0][~m])

@@ -1,0 +1,210 @@
+"""Pins the CPU restatement (oracle/cpu_ref.c) before anything trusts it.
+
+1. Against golden vectors produced by the REAL reference functions (tests/golden/*.npz, made by
+   tests/golden/make_golden.py from oracle/_ref/libref.so): Moller-Trumbore, triangle min/max, Lambert
+   shader, vector math -- bit for bit.
+2. Live against oracle/_ref/libref.so where it exists (authoring container and, because the built .so
+   travels, the GPU box) on fresh random inputs.
+3. Against the reference run outputs recorded in SURVEY.md Appendix C / section 6 (the voxelizer and the
+   DDA loop cannot be compiled here without spdlog, so these recorded numbers are their only pin).
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracer_amd import meshgen
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def orc_mt(tris, dirs, orgs):
+    l = oracle.lib()
+    n = tris.shape[0]
+    hit = np.zeros(n, np.int32)
+    t = np.zeros(n, np.float32)
+    for i in range(n):
+        tt = C.c_float(0)
+        hit[i] = l.orc_ray_triangle(C.c_void_p(tris.ctypes.data + 48 * i), C.c_void_p(dirs.ctypes.data + 12 * i),
+                                    C.c_void_p(orgs.ctypes.data + 12 * i), C.byref(tt))
+        t[i] = tt.value if hit[i] else 0.0
+    return hit, t
+
+
+def test_moller_trumbore_golden():
+    z = np.load(os.path.join(G, "mt_vectors.npz"))
+    tris, dirs, orgs = (np.ascontiguousarray(z[k]) for k in ("tris", "dirs", "orgs"))
+    hit, t = orc_mt(tris, dirs, orgs)
+    assert np.array_equal(hit, z["hit"])
+    assert np.array_equal(t.view(np.uint32), z["t_bits"])
+    assert 0 < hit.sum() < hit.size
+
+
+def test_triangle_min_max_golden():
+    z = np.load(os.path.join(G, "minmax_vectors.npz"))
+    tris = np.ascontiguousarray(z["tris"])
+    mn = np.zeros((tris.shape[0], 3), np.float32)
+    mx = np.zeros_like(mn)
+    for i in range(tris.shape[0]):
+        oracle.lib().orc_triangle_min_max(C.c_void_p(tris.ctypes.data + 48 * i), C.c_void_p(mn.ctypes.data + 12 * i),
+                                          C.c_void_p(mx.ctypes.data + 12 * i))
+    assert np.array_equal(mn.view(np.uint32), z["mn_bits"])
+    assert np.array_equal(mx.view(np.uint32), z["mx_bits"])
+
+
+def test_lambert_golden():
+    z = np.load(os.path.join(G, "lambert_vectors.npz"))
+    tris, og = np.ascontiguousarray(z["tris"]), np.ascontiguousarray(z["origins"])
+    out = np.zeros((tris.shape[0], 3), np.float32)
+    h = np.zeros(1, oracle.HIT_DTYPE)
+    for i in range(tris.shape[0]):
+        h["hit"] = 1
+        h["point"] = tris[i, :3]
+        h["origin"] = og[i]
+        h["normal"] = tris[i, 9:]
+        oracle.lib().orc_shade(None, _p(h), C.c_float(0.5), C.c_void_p(out.ctypes.data + 12 * i))
+    assert np.array_equal(out.view(np.uint32), z["rgb_bits"])
+
+
+def test_vector_math_golden():
+    # normalize / cross / dot are static inside cpu_ref.c; they are exercised through the camera frame:
+    # here the golden vectors pin numpy restatements of the same expressions, which test_camera_frame
+    # then compares with orc_camera_frame_make.
+    z = np.load(os.path.join(G, "vecmath_vectors.npz"))
+    a, b = z["a"], z["b"]
+    f = np.float32
+    dot = ((a[:, 0] * b[:, 0]).astype(f) + (a[:, 1] * b[:, 1]).astype(f)).astype(f) + (a[:, 2] * b[:, 2]).astype(f)
+    assert np.array_equal(dot.astype(f).view(np.uint32), z["dot_bits"])
+    crs = np.stack([(a[:, 1] * b[:, 2]).astype(f) - (a[:, 2] * b[:, 1]).astype(f),
+                    (a[:, 2] * b[:, 0]).astype(f) - (a[:, 0] * b[:, 2]).astype(f),
+                    (a[:, 0] * b[:, 1]).astype(f) - (a[:, 1] * b[:, 0]).astype(f)], 1).astype(f)
+    assert np.array_equal(crs.view(np.uint32), z["cross_bits"])
+    l2 = ((a[:, 0] * a[:, 0]).astype(f) + (a[:, 1] * a[:, 1]).astype(f)).astype(f) + (a[:, 2] * a[:, 2]).astype(f)
+    ln = np.sqrt(l2.astype(f)).astype(f)
+    with np.errstate(all="ignore"):
+        nrm = np.where((ln > 0)[:, None], (a / ln[:, None]).astype(f), a)
+    assert np.array_equal(nrm.astype(f).view(np.uint32), z["normalize_bits"])
+
+
+def _np_frame(pos, la, up, fov, aspect):
+    f = np.float32
+
+    def norm(v):
+        ln = np.sqrt(f(f(f(v[0] * v[0]) + f(v[1] * v[1])) + f(v[2] * v[2])))
+        return (v / ln).astype(f) if ln > 0 else v
+
+    def cross(a, b):
+        return np.array([f(a[1] * b[2]) - f(a[2] * b[1]), f(a[2] * b[0]) - f(a[0] * b[2]),
+                         f(a[0] * b[1]) - f(a[1] * b[0])], f)
+
+    pos, la, up = (np.asarray(x, f) for x in (pos, la, up))
+    fov_rad = f(f(f(fov) * f(3.14159265)) / f(180.0))
+    hh = f(math.tan(float(f(fov_rad / f(2.0)))))   # glibc tanf is correctly rounded from double tan here
+    hw = f(f(aspect) * hh)
+    fwd = norm((la - pos).astype(f))
+    right = norm(cross(fwd, up))
+    upv = cross(right, fwd)
+    hor = (right * f(f(2.0) * hw)).astype(f)
+    ver = (upv * f(f(2.0) * hh)).astype(f)
+    ll = (((pos - (hor * f(0.5)).astype(f)).astype(f) - (ver * f(0.5)).astype(f)).astype(f) + fwd).astype(f)
+    return np.concatenate([pos, ll, hor, ver]).astype(f)
+
+
+@pytest.mark.parametrize("view", ["front", "side", "top"])
+def test_camera_frame_restatement(view):
+    from raytracer_amd import capi
+    pos, la, up, fov, asp = capi.default_camera([-1, -0.5, -2], [1, 0.7, 2.5], view)
+    fr = oracle.frame_to_array(oracle.camera_frame(pos, la, up, fov, asp))
+    ref = _np_frame(pos, la, up, fov, asp)
+    # tanf vs double tan may differ in the last bit on other libms; everything else must be exact
+    assert np.allclose(fr, ref, rtol=2e-7, atol=0)
+    assert np.array_equal(fr[:3], ref[:3])
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref/libref.so not built (needs /root/reference)")
+def test_moller_trumbore_live_vs_reference():
+    rng = np.random.default_rng(7)
+    n = 20000
+    v = rng.uniform(-1, 1, (n, 3, 3)).astype(np.float32)
+    w = rng.dirichlet([1, 1, 1], n)
+    w = np.where(rng.random((n, 1)) < 0.6, w, rng.uniform(-0.2, 1.2, (n, 3)))
+    target = (w[:, :, None] * v).sum(1) / w.sum(1, keepdims=True)
+    o = rng.uniform(-3, 3, (n, 3))
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tris = np.concatenate([v.reshape(n, 9), np.zeros((n, 3), np.float32)], 1).astype(np.float32)
+    dirs, orgs = d.astype(np.float32), o.astype(np.float32)
+    rh, rt = oracle.ref_ray_triangle_batch(tris, dirs, orgs)
+    oh, ot = orc_mt(tris, dirs, orgs)
+    rt = np.where(rh == 1, rt, 0).astype(np.float32)
+    assert np.array_equal(rh, oh)
+    assert np.array_equal(rt.view(np.uint32), ot.view(np.uint32))
+
+
+# ---------------------------------------------------------------- SURVEY.md Appendix C (recorded reference run)
+
+def _appendix_c_mesh():
+    soup = meshgen.uv_sphere_soup(100, 200, 1.0)
+    # STLReader.h:506-518: drop triangles whose corners are not three distinct vertices (exact float equality)
+    a, b, c = soup[:, 0], soup[:, 1], soup[:, 2]
+    keep = ~((a == b).all(1) | (a == c).all(1) | (b == c).all(1))
+    kept = soup[keep]
+    verts = np.unique(soup.reshape(-1, 3), axis=0)
+    return meshgen.to_aos(kept), verts
+
+
+def test_survey_appendix_c_recorded_reference_outputs():
+    """Mesh, grid and camera of SURVEY.md Appendix C (39 800-tri sin/cos sphere, 50^3, 800x600, front
+    camera).  Expected values are the real reference's outputs recorded there; libm-dependent mesh."""
+    tris, verts = _appendix_c_mesh()
+    if tris.shape[0] != 39800 or verts.shape[0] != 20101:
+        pytest.skip("this libm's sin/cos give a different sphere than the survey machine's")
+    sc, mn, mx, vs = oracle.build_scene(tris, 50, 50, 50, points=verts)
+    cnt = np.diff(sc.offsets.astype(np.int64))
+    assert sc.indices.size == 144331                 # "CSR: refs 144 331"
+    assert int((cnt > 0).sum()) == 14960             # "occupied 14 960 / 125 000"
+    assert int(cnt.max()) == 504                     # "longest list 504 (pole voxels)"
+    # strictly ascending lists, x-fastest exclusive scan (F3)
+    for v in np.flatnonzero(cnt > 1)[:2000]:
+        seg = sc.indices[sc.offsets[v]:sc.offsets[v + 1]]
+        assert (np.diff(seg.astype(np.int64)) > 0).all()
+    from raytracer_amd import capi
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, "front")
+    fr = oracle.camera_frame(pos, la, up, fov, asp)
+    W, H = 800, 600
+    rgb, hit, t, c = sc.render(fr, W, H, threads=8)
+    miss = 0xFFFFFFFF
+    assert int((hit != miss).sum()) == 35137         # "hits 35 137 / 480 000 (7.32 %)"
+    assert abs(c[0] / (W * H) - 37.9) < 0.05         # "37.9 voxels/ray"
+    assert abs(c[1] / (W * H) - 111.1) < 0.05        # "111.1 tri-tests/ray"
+    assert hit[320, 400] == 18100                    # px(400,320) -> hit tri 18100
+    assert hit[320, 401] == 18099                    # px(401,320) -> hit tri 18099
+    assert hit[300, 410] == miss                     # px(410,300) dir.y=+0 -> MISS inside the silhouette (F7)
+    assert hit[300, 300] == miss                     # px(300,300) likewise
+    assert hit[300, 400] != miss                     # px(400,300) hits
+    assert abs(float(rgb[300, 400, 0]) - 1.09975) < 5e-6   # "probe centre pixel = 1.09975"
+    # per-pixel probes: voxels visited / tests (Appendix C lines)
+    o = np.array([fr.origin.x, fr.origin.y, fr.origin.z], np.float32)
+
+    def probe(x, y):
+        d = np.zeros(3, np.float32)
+        oracle.lib().orc_generate_ray(C.byref(fr), C.c_float(np.float32(x) / np.float32(W)),
+                                      C.c_float(np.float32(y) / np.float32(H)), _p(d))
+        out, cc = sc.trace(o[None], d[None])
+        return out[0], cc
+
+    h, cc = probe(400, 300)
+    assert h["hit"] == 1 and cc[0] == 1 and cc[1] == 18      # "hit, 1 voxel, 18 tests"
+    h, cc = probe(400, 320)
+    assert h["triangle_index"] == 18100 and cc[0] == 4       # "4 voxels"
+    h, cc = probe(401, 320)
+    assert h["triangle_index"] == 18099 and cc[0] == 5       # "5 voxels (spurious first X step)"
+    h, cc = probe(410, 300)
+    assert h["hit"] == 0 and cc[0] == 50                     # "MISS ..., 50 voxels (X never steps)"
