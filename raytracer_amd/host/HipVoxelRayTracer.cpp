@@ -1,0 +1,171 @@
+// HipVoxelRayTracer.cpp -- see the header.  Plain C++17, links libhvrt; no HIP headers.
+#include "HipVoxelRayTracer.hpp"
+
+#include <cstring>
+#include <stdexcept>
+
+#include "Logger.hpp"
+#include "hvrt.h"
+
+using namespace cg_datastructures;
+
+static_assert(sizeof(Triangle) == 48 && sizeof(Vec3) == 12, "Triangle must be the 12-float AoS record");
+
+namespace {
+[[noreturn]] void raise(hvrt_ctx* c, const char* what) {
+    throw std::runtime_error(std::string(what) + ": " + hvrt_last_error(c));
+}
+inline void ck(hvrt_ctx* c, int rc, const char* what) {
+    if (rc != HVRT_OK) raise(c, what);
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ HipScene
+
+HipScene::HipScene(int device_id) {
+    if (hvrt_create(&ctx_, device_id) != HVRT_OK) raise(nullptr, "hvrt_create");
+}
+
+HipScene::~HipScene() { hvrt_destroy(ctx_); }
+
+void HipScene::setTriangles(const std::vector<Triangle>& tris) {
+    tris_ = tris;
+    ck(ctx_, hvrt_set_mesh(ctx_, tris.empty() ? nullptr : &tris[0].v0.x, (uint32_t)tris.size()), "hvrt_set_mesh");
+}
+
+void HipScene::buildGrid(int nx, int ny, int nz, const Vec3& mn, const Vec3& mx, const Vec3& vs) {
+    ck(ctx_, hvrt_build_grid(ctx_, nx, ny, nz, &mn.x, &mx.x, &vs.x), "hvrt_build_grid");
+}
+
+void HipScene::computeBounds(const float* xyz, size_t n, Vec3& mn, Vec3& mx) {
+    ck(ctx_, hvrt_compute_bounds(ctx_, xyz, n, &mn.x, &mx.x), "hvrt_compute_bounds");
+}
+
+void HipScene::setGrid(const VoxelGrid& g) {
+    setTriangles(g.triangles);
+    const size_t nvox = (size_t)g.nx * g.ny * g.nz;
+    size_t refs = 0;
+    for (int x = 0; x < g.nx; ++x)
+        for (int y = 0; y < g.ny; ++y)
+            for (int z = 0; z < g.nz; ++z) refs += g.voxels[x][y][z].triangle_count;
+    if (refs > 0 && g.triangle_indices.empty()) {
+        // a grid read back from a .voxgrid file has no index array (TraceImages.cpp:447-448): the CSR is
+        // a deterministic function of (triangles, bounds, voxel size), so rebuild it on the GPU.
+        LOG_WARN("[HipVoxelGrid] grid has no triangle_indices; rebuilding the CSR on the GPU");
+        buildGrid(g.nx, g.ny, g.nz, g.minBound, g.maxBound, g.voxelSize);
+        return;
+    }
+    // voxels[x][y][z] -> flat order ix + nx*(iy + ny*iz); copy each list so that any start layout works
+    std::vector<uint32_t> offsets(nvox + 1), indices;
+    indices.reserve(refs);
+    size_t f = 0;
+    for (int z = 0; z < g.nz; ++z)
+        for (int y = 0; y < g.ny; ++y)
+            for (int x = 0; x < g.nx; ++x, ++f) {
+                const Voxel& v = g.voxels[x][y][z];
+                offsets[f] = (uint32_t)indices.size();
+                if ((size_t)v.triangle_start_idx + v.triangle_count > g.triangle_indices.size())
+                    throw std::runtime_error("VoxelGrid: voxel list runs past triangle_indices");
+                indices.insert(indices.end(), g.triangle_indices.begin() + v.triangle_start_idx,
+                               g.triangle_indices.begin() + v.triangle_start_idx + v.triangle_count);
+            }
+    offsets[nvox] = (uint32_t)indices.size();
+    ck(ctx_, hvrt_set_grid_csr(ctx_, g.nx, g.ny, g.nz, &g.minBound.x, &g.maxBound.x, &g.voxelSize.x, offsets.data(),
+                               indices.empty() ? nullptr : indices.data()), "hvrt_set_grid_csr");
+}
+
+VoxelGrid HipScene::downloadGrid() const {
+    hvrt_grid_info gi;
+    ck(ctx_, hvrt_get_grid_info(ctx_, &gi), "hvrt_get_grid_info");
+    std::vector<uint32_t> offsets(gi.n_voxels + 1), indices(gi.n_refs);
+    ck(ctx_, hvrt_get_csr(ctx_, offsets.data(), indices.empty() ? nullptr : indices.data()), "hvrt_get_csr");
+    std::vector<std::vector<std::vector<Voxel>>> vox(gi.nx, std::vector<std::vector<Voxel>>(gi.ny, std::vector<Voxel>(gi.nz)));
+    size_t f = 0;
+    for (int z = 0; z < gi.nz; ++z)
+        for (int y = 0; y < gi.ny; ++y)
+            for (int x = 0; x < gi.nx; ++x, ++f) {
+                Voxel& v = vox[x][y][z];
+                v.triangle_start_idx = offsets[f];
+                v.triangle_count = offsets[f + 1] - offsets[f];
+                v.occupied = v.triangle_count > 0;
+            }
+    Vec3 mn{ gi.min_bound[0], gi.min_bound[1], gi.min_bound[2] }, mx{ gi.max_bound[0], gi.max_bound[1], gi.max_bound[2] };
+    Vec3 vs{ gi.voxel_size[0], gi.voxel_size[1], gi.voxel_size[2] };
+    std::vector<Triangle> tris = tris_;
+    std::vector<unsigned int> idx(indices.begin(), indices.end());
+    return VoxelGrid(std::move(vox), std::move(idx), gi.nx, gi.ny, gi.nz, mn, mx, vs, std::move(tris));
+}
+
+double HipScene::lastBuildMs() const {
+    hvrt_timings t;
+    hvrt_get_timings(ctx_, &t);
+    return t.build_total_ms;
+}
+double HipScene::lastRenderMs() const {
+    hvrt_timings t;
+    hvrt_get_timings(ctx_, &t);
+    return t.render_ms;
+}
+
+// --------------------------------------------------------------------------------- HipVoxelRayTracer
+
+HipVoxelRayTracer::HipVoxelRayTracer(const VoxelGrid& grid, int, int) : scene_(std::make_shared<HipScene>(0)) {
+    LOG_INFO("[{}] Uploading voxel grid {}x{}x{} ({} triangles) to the GPU", getMethodName(), grid.nx, grid.ny, grid.nz,
+             grid.triangles.size());
+    scene_->setGrid(grid);
+}
+
+HipVoxelRayTracer::HipVoxelRayTracer(std::shared_ptr<HipScene> scene) : scene_(std::move(scene)) {
+    if (!scene_) throw std::runtime_error("HipVoxelRayTracer: null scene");
+}
+
+std::vector<Vec3> HipVoxelRayTracer::render(const Camera& cam, int width, int height) {
+    if (width <= 0 || height <= 0) throw std::runtime_error("render: width and height must be positive");
+    hvrt_camera_frame fr;
+    hvrt_make_camera_frame(&cam.position.x, &cam.lookAt.x, &cam.up.x, cam.fov, cam.aspectRatio, &fr);
+    std::vector<Vec3> frame((size_t)width * height);
+    hit_ids_.assign((size_t)width * height, HVRT_MISS);
+    uint64_t counters[2] = { 0, 0 };
+    LOG_INFO("[{}] Rendering {}x{} image...", getMethodName(), width, height);
+    ck(scene_->handle(), hvrt_render(scene_->handle(), &fr, width, height, 1, 0, &frame[0].x, hit_ids_.data(), nullptr, counters),
+       "hvrt_render");
+    voxels_ = counters[0];
+    tests_ = counters[1];
+    size_t hits = 0;
+    for (unsigned int h : hit_ids_) hits += h != HVRT_MISS;
+    const double total = (double)width * height;
+    // same statistics lines as OctreeLikeRayTracer.cpp:57-65 (counted once per ray, not twice)
+    LOG_INFO("[{}] Rendering complete! kernel {:.3f} ms", getMethodName(), scene_->lastRenderMs());
+    LOG_INFO("[{}] Ray hits: {} / {} ({:.1f}%)", getMethodName(), hits, (size_t)total, 100.0 * hits / total);
+    LOG_INFO("[{}] Voxels traversed: {}, Avg per ray: {:.1f}", getMethodName(), voxels_, voxels_ / total);
+    LOG_INFO("[{}] Triangle tests: {}, Avg per ray: {:.1f}", getMethodName(), tests_, tests_ / total);
+    return frame;
+}
+
+std::vector<RayHit> HipVoxelRayTracer::traceRays(const std::vector<Ray>& rays) {
+    const size_t n = rays.size();
+    std::vector<float> o(3 * n), d(3 * n);
+    for (size_t i = 0; i < n; ++i) {
+        std::memcpy(&o[3 * i], &rays[i].origin.x, 12);
+        std::memcpy(&d[3 * i], &rays[i].direction.x, 12);
+    }
+    std::vector<hvrt_hit> h(n);
+    uint64_t counters[2] = { 0, 0 };
+    ck(scene_->handle(), hvrt_trace(scene_->handle(), o.data(), d.data(), (uint32_t)n, h.data(), counters), "hvrt_trace");
+    voxels_ += counters[0];
+    tests_ += counters[1];
+    std::vector<RayHit> out(n);
+    for (size_t i = 0; i < n; ++i) {
+        RayHit& r = out[i];
+        r.hit = h[i].hit != 0;
+        r.t = h[i].t;
+        r.point = { h[i].point[0], h[i].point[1], h[i].point[2] };
+        r.origin = { h[i].origin[0], h[i].origin[1], h[i].origin[2] };
+        r.normal = { h[i].normal[0], h[i].normal[1], h[i].normal[2] };
+        r.triangleIndex = h[i].triangle_index;
+        r.voxelIndex = h[i].voxel_index;
+    }
+    return out;
+}
+
+RayHit HipVoxelRayTracer::traceRay(const Ray& ray) { return traceRays({ ray })[0]; }

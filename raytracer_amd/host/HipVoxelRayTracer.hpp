@@ -1,0 +1,69 @@
+// HipVoxelRayTracer.hpp -- IRayTracer on the MI355X through libhvrt's C ABI (include/hvrt.h).
+//
+// Drop-in for OctreeLikeRayTracer (OctreeRayTracer.h:28-79): same constructor shape, same three
+// virtuals, same results.  Errors from the C ABI become std::runtime_error, which TraceImage catches
+// and logs exactly like any other exception (TraceImages.cpp:69-74).  This header needs no HIP header.
+#pragma once
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "IRayTracer.hpp"
+
+struct hvrt_ctx;
+
+// A scene resident on one GPU: triangles + CSR grid.  Shared by tracers so that TraceImageMultiView's
+// three views (TraceImages.cpp:77-119) reuse one upload / one build.
+class HipScene {
+public:
+    explicit HipScene(int device_id = 0);
+    ~HipScene();
+    HipScene(const HipScene&) = delete;
+    HipScene& operator=(const HipScene&) = delete;
+
+    // Upload triangles and build the grid ON THE GPU (replaces voxelizeTrianglesDirect,
+    // SceneCreator.cpp:197-281).  minBound / maxBound / voxelSize as computeVoxelizationParams gives.
+    void setTriangles(const std::vector<cg_datastructures::Triangle>& tris);
+    void buildGrid(int nx, int ny, int nz, const cg_datastructures::Vec3& mn, const cg_datastructures::Vec3& mx,
+                   const cg_datastructures::Vec3& voxelSize);
+    // Ingest a CPU-built VoxelGrid (flattens voxels[x][y][z] to the x-fastest CSR).  A grid whose
+    // triangle_indices are missing (a .voxgrid file, TraceImages.cpp:447-448) is rebuilt on the GPU.
+    void setGrid(const VoxelGrid& grid);
+    // GPU bounds of a vertex list (computeMeshBounds, SceneCreator.cpp:49-84).
+    void computeBounds(const float* xyz, size_t n_points, cg_datastructures::Vec3& mn, cg_datastructures::Vec3& mx);
+    // Copy the GPU-built CSR back into the reference's container (voxels[x][y][z] + triangle_indices).
+    VoxelGrid downloadGrid() const;
+
+    hvrt_ctx* handle() const { return ctx_; }
+    double lastBuildMs() const;
+    double lastRenderMs() const;
+
+private:
+    hvrt_ctx* ctx_ = nullptr;
+    std::vector<cg_datastructures::Triangle> tris_;   // host copy (downloadGrid returns them)
+};
+
+class HipVoxelRayTracer : public IRayTracer {
+public:
+    // Same shape as OctreeLikeRayTracer(const VoxelGrid&, int, int): uploads the CPU-built grid.
+    explicit HipVoxelRayTracer(const VoxelGrid& grid, int maxDepth = 8, int maxTrianglesPerNode = 10);
+    // Scene already resident (built on the GPU): no upload.
+    explicit HipVoxelRayTracer(std::shared_ptr<HipScene> scene);
+    ~HipVoxelRayTracer() override = default;
+
+    std::vector<cg_datastructures::Vec3> render(const cg_datastructures::Camera& camera, int width, int height) override;
+    cg_datastructures::RayHit traceRay(const cg_datastructures::Ray& ray) override;
+    std::string getMethodName() const override { return "HipVoxelGrid"; }
+
+    // Batched traceRay and the statistics the reference logs (OctreeLikeRayTracer.cpp:57-65).
+    std::vector<cg_datastructures::RayHit> traceRays(const std::vector<cg_datastructures::Ray>& rays);
+    unsigned long long voxelsTraversed() const { return voxels_; }
+    unsigned long long triangleTests() const { return tests_; }
+    const std::vector<unsigned int>& lastHitIds() const { return hit_ids_; }
+
+private:
+    std::shared_ptr<HipScene> scene_;
+    unsigned long long voxels_ = 0, tests_ = 0;
+    std::vector<unsigned int> hit_ids_;
+};

@@ -1,0 +1,101 @@
+// ImageWriter.hpp -- PPM and PNG output of a float framebuffer with the reference's quantisation
+// (ImageSaver.h:18-75): byte = (uint8_t)clamp(c * 255.0f, 0.0f, 255.0f) (truncation), pixels written in
+// framebuffer order.  The PNG is a valid stored-deflate (uncompressed) stream; JPEG is not provided
+// (image encoding is I/O outside the hot path) and ".jpg" names are written as PPM bytes.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "rt_types.hpp"
+
+namespace cg_datastructures {
+
+inline std::vector<uint8_t> quantise(const std::vector<Vec3>& px) {
+    std::vector<uint8_t> out(px.size() * 3);
+    for (size_t i = 0; i < px.size(); ++i) {
+        out[3 * i + 0] = static_cast<uint8_t>(std::clamp(px[i].x * 255.0f, 0.0f, 255.0f));
+        out[3 * i + 1] = static_cast<uint8_t>(std::clamp(px[i].y * 255.0f, 0.0f, 255.0f));
+        out[3 * i + 2] = static_cast<uint8_t>(std::clamp(px[i].z * 255.0f, 0.0f, 255.0f));
+    }
+    return out;
+}
+
+inline bool saveToPPM(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
+    std::ofstream f(filename, std::ios::binary);
+    if (!f) return false;
+    f << "P6\n" << width << " " << height << "\n255\n";
+    std::vector<uint8_t> q = quantise(pixels);
+    f.write(reinterpret_cast<const char*>(q.data()), (std::streamsize)q.size());
+    return (bool)f;
+}
+
+namespace png_detail {
+inline uint32_t crc32(const uint8_t* p, size_t n, uint32_t crc = 0) {
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    crc = ~crc;
+    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    return ~crc;
+}
+inline void be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x);
+}
+inline void chunk(std::ofstream& f, const char* type, const std::vector<uint8_t>& data) {
+    std::vector<uint8_t> buf;
+    be32(buf, (uint32_t)data.size());
+    buf.insert(buf.end(), type, type + 4);
+    buf.insert(buf.end(), data.begin(), data.end());
+    uint32_t c = crc32(buf.data() + 4, buf.size() - 4);
+    be32(buf, c);
+    f.write(reinterpret_cast<const char*>(buf.data()), (std::streamsize)buf.size());
+}
+}  // namespace png_detail
+
+inline bool saveToPNG(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
+    using namespace png_detail;
+    std::ofstream f(filename, std::ios::binary);
+    if (!f) return false;
+    const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', '\r', '\n', 0x1A, '\n' };
+    f.write(reinterpret_cast<const char*>(sig), 8);
+    std::vector<uint8_t> ihdr;
+    be32(ihdr, (uint32_t)width);
+    be32(ihdr, (uint32_t)height);
+    ihdr.insert(ihdr.end(), { 8, 2, 0, 0, 0 });   // 8-bit RGB
+    chunk(f, "IHDR", ihdr);
+    std::vector<uint8_t> q = quantise(pixels), raw;
+    raw.reserve(((size_t)width * 3 + 1) * height);
+    for (int y = 0; y < height; ++y) {
+        raw.push_back(0);   // filter: none
+        raw.insert(raw.end(), q.begin() + (size_t)y * width * 3, q.begin() + (size_t)(y + 1) * width * 3);
+    }
+    std::vector<uint8_t> z = { 0x78, 0x01 };
+    uint32_t a = 1, b = 0;   // adler32
+    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+        size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);
+        z.push_back(n & 0xFF); z.push_back(n >> 8);
+        z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
+        z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+        for (size_t i = 0; i < n; ++i) { a = (a + raw[pos + i]) % 65521; b = (b + a) % 65521; }
+        pos += n;
+        if (n == 0) break;
+    }
+    be32(z, (b << 16) | a);
+    chunk(f, "IDAT", z);
+    chunk(f, "IEND", {});
+    return (bool)f;
+}
+
+}  // namespace cg_datastructures

@@ -1,0 +1,222 @@
+// TraceImages.cpp -- host pipeline around the GPU hot path; see TraceImages.hpp.
+#include "TraceImages.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <stdexcept>
+
+#include "ImageWriter.hpp"
+#include "Logger.hpp"
+#include "hvrt.h"
+
+using namespace cg_datastructures;
+namespace fs = std::filesystem;
+
+namespace {
+double seconds_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+std::string lower_ext(const std::string& path) {
+    std::string e = fs::path(path).extension().string();
+    std::transform(e.begin(), e.end(), e.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+    return e;
+}
+}  // namespace
+
+std::string TraceImages::getRayTracingMethodName(RayTracingMethod m) {
+    switch (m) {
+        case RayTracingMethod::VOXEL_DDA: return "Voxel Grid DDA";
+        case RayTracingMethod::ART: return "ARTS (3DDDA)";
+        case RayTracingMethod::OCTREE: return "Octree";
+        case RayTracingMethod::HIP_VOXEL: return "HIP Voxel Grid (MI355X)";
+    }
+    return "Unknown";
+}
+
+// ---------------------------------------------------------------------------------------- scene build
+
+VoxelGrid TraceImages::buildSceneOnGpu(const stl_reader::StlMesh<float, unsigned int>& mesh, int nx, int ny, int nz,
+                                       HipScene& scene) {
+    // computeMeshBounds over the de-duplicated vertex list (SceneCreator.cpp:49-84) -- on the GPU
+    Vec3 mn{}, mx{};
+    scene.computeBounds(mesh.raw_coords(), mesh.num_vrts(), mn, mx);
+    // computeVoxelizationParams (SceneCreator.cpp:91-122)
+    const float vs = hvrt_voxel_size(&mn.x, &mx.x, nx, ny, nz);
+    // buildTriangleList (SceneCreator.cpp:129-170): gather corners + file normal
+    std::vector<Triangle> tris(mesh.num_tris());
+    for (size_t t = 0; t < tris.size(); ++t) {
+        std::memcpy(&tris[t].v0, mesh.tri_corner_coords(t, 0), 12);
+        std::memcpy(&tris[t].v1, mesh.tri_corner_coords(t, 1), 12);
+        std::memcpy(&tris[t].v2, mesh.tri_corner_coords(t, 2), 12);
+        std::memcpy(&tris[t].normal, mesh.tri_normal(t), 12);
+    }
+    scene.setTriangles(tris);
+    // voxelizeTrianglesDirect (SceneCreator.cpp:197-281) -- on the GPU
+    scene.buildGrid(nx, ny, nz, mn, mx, Vec3{ vs, vs, vs });
+    LOG_INFO("Voxel grid built on the GPU in {:.3f} ms ({} triangles)", scene.lastBuildMs(), tris.size());
+    return VoxelGrid({}, {}, nx, ny, nz, mn, mx, Vec3{ vs, vs, vs }, {});
+}
+
+TraceImages::Loaded TraceImages::loadOrGenerate(const std::string& path, int nx, int ny, int nz, RayTracingMethod method) {
+    const std::string ext = lower_ext(path);
+    if (ext != ".voxgrid" && ext != ".stl") {
+        LOG_ERROR("Unsupported file format: {}. Expected .stl or .voxgrid", ext);
+        throw std::runtime_error("Unsupported file format: " + ext);      // TraceImages.cpp:351-352
+    }
+    if (method != RayTracingMethod::HIP_VOXEL)
+        throw std::runtime_error("method '" + getRayTracingMethodName(method) +
+                                 "' is the reference's CPU tracer, which this library does not contain; use HIP_VOXEL");
+    Loaded l;
+    l.scene = std::make_shared<HipScene>(0);
+    if (ext == ".voxgrid") {
+        LOG_INFO("Loading pre-saved voxel grid from: {}", path);
+        l.grid = VoxelGrid::loadFromFile(path);
+        l.scene->setGrid(l.grid);
+    } else {
+        LOG_INFO("Processing STL file: {}", path);
+        stl_reader::StlMesh<float, unsigned int> mesh(path);
+        LOG_INFO("Loaded mesh with {} triangles", mesh.num_tris());
+        l.grid = buildSceneOnGpu(mesh, nx, ny, nz, *l.scene);
+    }
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------- cameras
+
+Camera TraceImages::setupCamera(const VoxelGrid& g) { return setupCameraWithView(g, CameraView::FRONT); }
+
+Camera TraceImages::setupCameraWithView(const VoxelGrid& g, CameraView view) {
+    // TraceImages.cpp:125-197: distance = 2.5 * largest extent, fov 60, aspect 800/600
+    const Vec3 c = g.center;
+    const float sx = g.maxBound.x - g.minBound.x, sy = g.maxBound.y - g.minBound.y, sz = g.maxBound.z - g.minBound.z;
+    const float dist = std::max({ sx, sy, sz }) * 2.5f;
+    Vec3 pos = c, up{ 0.0f, 1.0f, 0.0f };
+    switch (view) {
+        case CameraView::FRONT: pos.z = c.z - dist; break;
+        case CameraView::SIDE: pos.x = c.x + dist; break;
+        case CameraView::TOP: pos.y = c.y + dist; up = { 0.0f, 0.0f, 1.0f }; break;
+    }
+    return Camera(pos, c, up, 60.0f, 800.0f / 600.0f);
+}
+
+// ---------------------------------------------------------------------------------------- factory
+
+std::unique_ptr<IRayTracer> TraceImages::createRayTracer(VoxelGrid& voxelGrid, RayTracingMethod method) {
+    switch (method) {
+        case RayTracingMethod::HIP_VOXEL:
+            return std::make_unique<HipVoxelRayTracer>(voxelGrid);
+        default:
+            throw std::runtime_error("method '" + getRayTracingMethodName(method) +
+                                     "' is the reference's CPU tracer, which this library does not contain; use HIP_VOXEL");
+    }
+}
+
+// ---------------------------------------------------------------------------------------- pipeline
+
+void TraceImages::renderAndSave(Loaded& l, const Camera& cam, const std::string& filename, RayTracingMethod) {
+    HipVoxelRayTracer tracer(l.scene);
+    auto t0 = std::chrono::steady_clock::now();
+    lastPixels = tracer.render(cam, imageWidth, imageHeight);
+    lastHitIds = tracer.lastHitIds();
+    const double s = seconds_since(t0);
+    LOG_INFO("Rendered {} pixels in {:.3f}s ({:.0f} rays/sec)", lastPixels.size(), s, (imageWidth * (double)imageHeight) / s);
+    SaveImage(outputDirectory + filename, lastPixels, imageWidth, imageHeight);
+}
+
+void TraceImages::TraceImage(std::string gridFileLocation, std::string outputFileName, RayTracingMethod method) {
+    LOG_INFO("========== Starting image generation ==========");
+    LOG_INFO("Input: {} | Output: {} | Method: {}", gridFileLocation, outputFileName, getRayTracingMethodName(method));
+    auto t0 = std::chrono::steady_clock::now();
+    lastOk = false;
+    try {
+        Loaded l = loadOrGenerate(gridFileLocation, gridResolution, gridResolution, gridResolution, method);
+        LOG_INFO("Voxel grid generated with size: ({:.6f}, {:.6f}, {:.6f})", l.grid.voxelSize.x, l.grid.voxelSize.y, l.grid.voxelSize.z);
+        renderAndSave(l, setupCamera(l.grid), outputFileName, method);
+        LOG_INFO("Success! Generated {} in {:.3f}s", outputFileName, seconds_since(t0));
+        lastOk = true;
+    } catch (const std::exception& e) {
+        // as the reference: log and carry on with the next image (TraceImages.cpp:69-74)
+        LOG_ERROR("Failed: {} - {} (after {:.3f}s)", gridFileLocation, e.what(), seconds_since(t0));
+    }
+}
+
+void TraceImages::TraceImageMultiView(std::string gridFileLocation, std::string baseOutputName, RayTracingMethod method) {
+    LOG_INFO("========== Starting multi-view image generation ==========");
+    auto t0 = std::chrono::steady_clock::now();
+    lastOk = false;
+    try {
+        // the grid is built once and stays resident for all three views
+        Loaded l = loadOrGenerate(gridFileLocation, gridResolution, gridResolution, gridResolution, method);
+        const fs::path base(baseOutputName);
+        const std::string ext = base.extension().string(), stem = base.stem().string();
+        const std::pair<CameraView, const char*> views[] = { { CameraView::FRONT, "_front" }, { CameraView::SIDE, "_side" }, { CameraView::TOP, "_top" } };
+        for (const auto& [view, suffix] : views) {
+            auto tv = std::chrono::steady_clock::now();
+            renderAndSave(l, setupCameraWithView(l.grid, view), stem + suffix + ext, method);
+            LOG_INFO("View rendered in {:.3f}s", seconds_since(tv));
+        }
+        LOG_INFO("Success! Generated all views in {:.3f}s", seconds_since(t0));
+        lastOk = true;
+    } catch (const std::exception& e) {
+        LOG_ERROR("Failed: {} - {} (after {:.3f}s)", gridFileLocation, e.what(), seconds_since(t0));
+    }
+}
+
+void TraceImages::SaveImage(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
+    const fs::path p(filename);
+    if (!p.parent_path().empty() && !fs::exists(p.parent_path())) fs::create_directories(p.parent_path());
+    const std::string ext = lower_ext(filename);
+    bool ok;
+    if (ext == ".png") ok = saveToPNG(filename, pixels, width, height);
+    else {
+        if (ext != ".ppm") LOG_WARN("Extension '{}' is written as PPM bytes by this library", ext);
+        ok = saveToPPM(filename, pixels, width, height);
+    }
+    if (ok) LOG_INFO("Image saved: {}", filename); else LOG_ERROR("Failed to save: {}", filename);
+}
+
+// ---------------------------------------------------------------------------------------- .voxgrid
+
+// Byte layout of TraceImages.cpp:360-457: int nx,ny,nz; Vec3 min,max,voxelSize,center; Voxel (28 raw bytes)
+// for x { y { z } }; int triangle_count; Triangle[...] (48 bytes each).  triangle_indices are NOT in the file.
+bool VoxelGrid::saveToFile(const std::string& filename) const {
+    std::ofstream f(filename, std::ios::binary);
+    if (!f) return false;
+    auto put = [&](const void* p, size_t n) { f.write(static_cast<const char*>(p), (std::streamsize)n); };
+    put(&nx, 4); put(&ny, 4); put(&nz, 4);
+    put(&minBound, 12); put(&maxBound, 12); put(&voxelSize, 12); put(&center, 12);
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) put(&voxels[x][y][z], sizeof(Voxel));
+    const int n = (int)triangles.size();
+    put(&n, 4);
+    put(triangles.data(), (size_t)n * sizeof(Triangle));
+    return (bool)f;
+}
+
+VoxelGrid VoxelGrid::loadFromFile(const std::string& filename) {
+    std::ifstream f(filename, std::ios::binary);
+    if (!f) throw std::runtime_error("Failed to open file: " + filename);
+    auto get = [&](void* p, size_t n) {
+        f.read(static_cast<char*>(p), (std::streamsize)n);
+        if ((size_t)f.gcount() != n) throw std::runtime_error("Truncated voxel grid file: " + filename);
+    };
+    int nx, ny, nz;
+    Vec3 mn, mx, vs, center;
+    get(&nx, 4); get(&ny, 4); get(&nz, 4);
+    if (nx < 1 || ny < 1 || nz < 1 || (long long)nx * ny * nz > (1ll << 32)) throw std::runtime_error("Bad voxel grid dimensions in " + filename);
+    get(&mn, 12); get(&mx, 12); get(&vs, 12); get(&center, 12);
+    std::vector<std::vector<std::vector<Voxel>>> vox(nx, std::vector<std::vector<Voxel>>(ny, std::vector<Voxel>(nz)));
+    for (int x = 0; x < nx; ++x)
+        for (int y = 0; y < ny; ++y)
+            for (int z = 0; z < nz; ++z) get(&vox[x][y][z], sizeof(Voxel));
+    int n = 0;
+    get(&n, 4);
+    if (n < 0) throw std::runtime_error("Bad triangle count in " + filename);
+    std::vector<Triangle> tris((size_t)n);
+    get(tris.data(), (size_t)n * sizeof(Triangle));
+    return VoxelGrid(std::move(vox), {}, nx, ny, nz, mn, mx, vs, std::move(tris));
+}

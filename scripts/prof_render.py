@@ -1,0 +1,29 @@
+"""Short profiling target: config 2 scene, a few build + render launches (for rocprofv3 --pmc passes)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import raytracer_amd as ra
+from raytracer_amd import capi, meshgen
+
+n, g, W, H = 289, 256, 3840, 2160
+if len(sys.argv) > 1 and sys.argv[1] == "small":
+    n, g, W, H = 58, 50, 800, 600
+ctx = ra.Context(0)
+ctx.set_mesh(meshgen.cube_sphere(n))
+mn, mx = ctx.mesh_bounds()
+vs = capi.voxel_size(mn, mx, g, g, g)
+for _ in range(2):
+    ctx.build_grid(g, g, g, mn, mx, vs)
+pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
+cam = capi.make_camera_frame(pos, la, up, fov, asp)
+import torch
+rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0")
+hit = torch.empty((H, W), dtype=torch.int32, device="cuda:0")
+t = torch.empty((H, W), dtype=torch.float32, device="cuda:0")
+torch.cuda.synchronize()
+for _ in range(4):
+    ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
+    ctx.synchronize()
+print("render_ms", ctx.timings().render_ms, "build_ms", ctx.timings().build_total_ms)
+ctx.close()
