@@ -75,13 +75,15 @@ typedef struct hvrt_grid_info {
     uint32_t n_triangles;
 } hvrt_grid_info;
 
-/* Per-call device timings (HIP events on the context's stream), milliseconds. */
+/* Per-call device timings (HIP events on the context's stream), milliseconds.
+ * build_total_ms = count + scan + fill + order + expand. */
 typedef struct hvrt_timings {
     float build_total_ms;   /* hvrt_build_grid: count + scan + fill + order */
     float build_count_ms;
     float build_scan_ms;
     float build_fill_ms;
     float build_sort_ms;
+    float build_expand_ms;  /* per-reference traversal records (libhvrt's own acceleration data) */
     float render_ms;        /* last hvrt_render* traversal kernel(s) */
     float trace_ms;         /* last hvrt_trace */
 } hvrt_timings;

@@ -14,7 +14,7 @@ from dataclasses import dataclass
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhvrt.so")
+LIB_PATH = os.environ.get("HVRT_LIB") or os.path.join(_HERE, "lib", "libhvrt.so")
 
 HVRT_MISS = 0xFFFFFFFF
 
@@ -48,7 +48,8 @@ class GridInfo(C.Structure):
 
 class Timings(C.Structure):
     _fields_ = [("build_total_ms", C.c_float), ("build_count_ms", C.c_float), ("build_scan_ms", C.c_float),
-                ("build_fill_ms", C.c_float), ("build_sort_ms", C.c_float), ("render_ms", C.c_float),
+                ("build_fill_ms", C.c_float), ("build_sort_ms", C.c_float), ("build_expand_ms", C.c_float),
+                ("render_ms", C.c_float),
                 ("trace_ms", C.c_float)]
 
 

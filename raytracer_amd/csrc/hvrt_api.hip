@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -19,7 +20,7 @@ struct hvrt_ctx {
     int n_cus = 256;
     hipStream_t stream = nullptr;       // the stream all work is issued on (own_stream unless hvrt_set_stream)
     hipStream_t own_stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[10] = {};
     std::string error;
 
     // mesh
@@ -37,6 +38,13 @@ struct hvrt_ctx {
     uint64_t cnt_capacity = 0;     // u32 elements
     uint32_t* indices = nullptr;
     uint64_t indices_capacity = 0;
+    float4* ref_rec = nullptr;     // per-reference traversal records (n_refs x 48 B), see SceneDev
+    uint64_t ref_rec_capacity = 0; // float4s
+    bool inline_records = true;    // HVRT_INLINE_RECORDS=0 selects the indexed traversal
+    bool ref_rec_valid = false;
+    uint32_t* face_bits = nullptr; // 6 x face_words u32, see SceneDev
+    uint64_t face_bits_capacity = 0;
+    uint64_t face_words = 0;
     uint64_t n_refs = 0, n_occupied = 0;
     uint32_t max_list = 0;
 
@@ -131,12 +139,49 @@ SceneDev scene_of(const hvrt_ctx* c) {
     s.offsets = offsets_of(c);
     s.indices = c->indices;
     s.n_tris = c->n_tris;
+    s.ref_rec = c->ref_rec_valid ? c->ref_rec : nullptr;
+    s.face_bits = c->face_bits;
+    s.face_words = c->face_words;
     return s;
 }
 
 int require_scene(hvrt_ctx* c) {
     if (!c->n_tris && !c->tri_rec) return fail(c, HVRT_ERR_INVALID, "no mesh: call hvrt_set_mesh first");
     if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "no grid: call hvrt_build_grid or hvrt_set_grid_csr first");
+    return HVRT_OK;
+}
+
+// Builds the per-reference records (and validates every CSR index against the mesh).  Falls back to the
+// indexed traversal when switched off or when the array does not fit in device memory.
+int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate) {
+    c->ref_rec_valid = false;
+    // face bits: one bit per entry and face, padded by two words so that a 32-entry window read at the
+    // last entry stays inside the array
+    c->face_words = (c->n_refs + 63) / 64 * 2 + 2;
+    if (int r = ensure<uint32_t>(c, c->face_bits, c->face_bits_capacity, 6 * c->face_words)) return r;
+    HIP_TRY(c, launch_face_bits(c->indices, c->n_refs, offsets_of(c), c->g, c->n_tris, validate ? nullptr : c->ranges,
+                                c->face_bits, c->face_words, s));
+    if (c->n_refs == 0) return HVRT_OK;
+    const bool want = c->inline_records;
+    if (want) {
+        if (c->ref_rec_capacity < c->n_refs * 3) {
+            if (c->ref_rec) { (void)hipFree(c->ref_rec); c->ref_rec = nullptr; c->ref_rec_capacity = 0; }
+            hipError_t e = hipMalloc((void**)&c->ref_rec, c->n_refs * 48);
+            if (e == hipSuccess) c->ref_rec_capacity = c->n_refs * 3;
+            else { (void)hipGetLastError(); c->ref_rec = nullptr; }   // does not fit: indexed mode
+        }
+    }
+    if (!want || !c->ref_rec) return HVRT_OK;
+    HIP_TRY(c, hipMemsetAsync(c->stats + 4, 0, sizeof(uint64_t), s));
+    HIP_TRY(c, launch_expand_records(c->indices, c->n_refs, c->tri_rec, c->n_tris, c->ref_rec, c->stats, s));
+    uint64_t bad = 0;
+    if (validate) {   // ingested CSR: the indices come from the caller
+        HIP_TRY(c, hipMemcpyAsync(&bad, c->stats + 4, sizeof bad, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+    }
+    if (bad) return fail(c, HVRT_ERR_INVALID, "grid: %llu CSR entries reference a triangle index >= %u",
+                         (unsigned long long)bad, c->n_tris);
+    c->ref_rec_valid = true;
     return HVRT_OK;
 }
 
@@ -161,6 +206,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         return fail(nullptr, HVRT_ERR_INVALID, "device_id %d out of range (0..%d)", device_id, n - 1);
     hvrt_ctx* c = new hvrt_ctx();
     c->device = device_id;
+    if (const char* e = getenv("HVRT_INLINE_RECORDS")) c->inline_records = atoi(e) != 0;
     auto bail = [&](const char* what, hipError_t err) {
         fail(nullptr, HVRT_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
         hvrt_destroy(c);
@@ -188,7 +234,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ranges, c->block_sums, c->stats, c->long_queue,
+    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->ranges, c->block_sums, c->stats, c->long_queue,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -334,6 +380,9 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipEventRecord(c->ev[4], s));
     HIP_TRY(c, launch_sort(offsets_of(c), c->indices, nvox, c->long_queue, c->long_queue_capacity, c->stats, s));
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    c->n_refs = total;
+    if (int r = make_ref_records(c, s, false)) return r;
+    HIP_TRY(c, hipEventRecord(c->ev[8], s));
     HIP_TRY(c, hipStreamSynchronize(s));
 
     c->n_refs = total;
@@ -344,7 +393,8 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     c->tm.build_scan_ms = ms_between(c->ev[1], c->ev[2]);
     c->tm.build_fill_ms = ms_between(c->ev[3], c->ev[4]);
     c->tm.build_sort_ms = ms_between(c->ev[4], c->ev[5]);
-    c->tm.build_total_ms = ms_between(c->ev[0], c->ev[5]);
+    c->tm.build_expand_ms = ms_between(c->ev[5], c->ev[8]);
+    c->tm.build_total_ms = ms_between(c->ev[0], c->ev[8]);
     return HVRT_OK;
 }
 
@@ -370,6 +420,7 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
     c->n_refs = n_refs;
     c->n_occupied = h_stats[1];
     c->max_list = (uint32_t)h_stats[2];
+    if (int r = make_ref_records(c, s, true)) return r;
     c->has_grid = true;
     return HVRT_OK;
 }

@@ -338,6 +338,90 @@ __global__ __launch_bounds__(NT) void k_sort_long(const uint32_t* __restrict__ o
     }
 }
 
+// per-reference traversal records (SceneDev::ref_rec); also validates ingested indices (stats[4] = #bad)
+__global__ __launch_bounds__(256) void k_expand_records(const uint32_t* __restrict__ indices, uint64_t n_refs,
+                                                        const float4* __restrict__ tri_rec, uint32_t n_tris,
+                                                        float4* __restrict__ ref_rec, uint64_t* __restrict__ stats) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_refs) return;
+    const uint32_t ti = indices[j];
+    float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+    if (ti < n_tris) {
+        a = tri_rec[3ull * ti]; b = tri_rec[3ull * ti + 1]; c = tri_rec[3ull * ti + 2];
+    } else {
+        atomicAdd((unsigned long long*)&stats[4], 1ull);
+    }
+    ref_rec[3 * j] = a;
+    ref_rec[3 * j + 1] = b;
+    ref_rec[3 * j + 2] = make_float4(c.x, __uint_as_float(ti), 0.0f, 0.0f);
+}
+
+// face_bits (SceneDev): for CSR entry j in voxel (ix,iy,iz), bit f says that the entry's triangle is also
+// in the list of face neighbour f (0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z).  A clear bit is always safe.  For
+// grids built here a list is exactly the set of triangles whose AABB voxel range covers the voxel, so the
+// bits come from the stored ranges; for an ingested CSR they come from a binary search of the neighbour's
+// (ascending) list.  One lane per entry; a wave's 64 consecutive entries become one 64-bit word per face
+// (__ballot), so no atomics are needed.
+__device__ __forceinline__ bool list_contains(const uint32_t* __restrict__ indices, uint32_t b0, uint32_t b1, uint32_t ti) {
+    while (b0 < b1) {
+        const uint32_t m = b0 + ((b1 - b0) >> 1);
+        const uint32_t v = indices[m];
+        if (v == ti) return true;
+        if (v < ti) b0 = m + 1; else b1 = m;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_face_bits(const uint32_t* __restrict__ indices, uint64_t n_refs,
+                                                   const uint32_t* __restrict__ offsets, GridParams g, uint32_t n_tris,
+                                                   const uint32_t* __restrict__ ranges,
+                                                   uint32_t* __restrict__ face_bits, uint64_t face_words) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    uint32_t mask = 0;
+    if (j < n_refs) {
+        const uint32_t ti = indices[j];
+        if (ti < n_tris) {
+            // voxel of entry j: the last v with offsets[v] <= j
+            uint64_t lo = 0, hi = g.nvox;            // invariant: offsets[lo] <= j < offsets[hi]
+            while (hi - lo > 1) {
+                const uint64_t m = lo + ((hi - lo) >> 1);
+                if (offsets[m] <= (uint32_t)j) lo = m; else hi = m;
+            }
+            const uint64_t v = lo;
+            const uint32_t plane = (uint32_t)g.nx * (uint32_t)g.ny;
+            const int iz = (int)(v / plane);
+            const uint32_t rem = (uint32_t)(v - (uint64_t)iz * plane);
+            const int iy = (int)(rem / (uint32_t)g.nx), ix = (int)(rem - (uint32_t)iy * (uint32_t)g.nx);
+            if (ranges) {
+                const uint32_t rx = ranges[3ull * ti], ry = ranges[3ull * ti + 1], rz = ranges[3ull * ti + 2];
+                mask |= ((int)(rx & 0xFFFFu) < ix) ? 1u : 0u;
+                mask |= ((int)(rx >> 16) > ix) ? 2u : 0u;
+                mask |= ((int)(ry & 0xFFFFu) < iy) ? 4u : 0u;
+                mask |= ((int)(ry >> 16) > iy) ? 8u : 0u;
+                mask |= ((int)(rz & 0xFFFFu) < iz) ? 16u : 0u;
+                mask |= ((int)(rz >> 16) > iz) ? 32u : 0u;
+            } else {
+                const int64_t sv = (int64_t)v;
+                const int64_t nb[6] = { sv - 1, sv + 1, sv - g.nx, sv + g.nx, sv - (int64_t)plane, sv + (int64_t)plane };
+                const bool ok[6] = { ix > 0, ix + 1 < g.nx, iy > 0, iy + 1 < g.ny, iz > 0, iz + 1 < g.nz };
+#pragma unroll
+                for (int k = 0; k < 6; ++k)
+                    if (ok[k] && list_contains(indices, offsets[nb[k]], offsets[nb[k] + 1], ti)) mask |= 1u << k;
+            }
+        }
+    }
+    const uint64_t w = j >> 6;   // this wave's 64 entries
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const unsigned long long bits = __ballot((mask >> k) & 1u);
+        if ((threadIdx.x & 63) == 0 && 2 * w < face_words) {
+            uint32_t* dst = face_bits + (uint64_t)k * face_words + 2 * w;
+            dst[0] = (uint32_t)bits;
+            if (2 * w + 1 < face_words) dst[1] = (uint32_t)(bits >> 32);
+        }
+    }
+}
+
 // occupancy statistics of an ingested CSR (hvrt_set_grid_csr*)
 __global__ __launch_bounds__(256) void k_csr_stats(const uint32_t* __restrict__ offsets, uint64_t nvox,
                                                    uint64_t* __restrict__ stats) {
@@ -483,6 +567,23 @@ hipError_t launch_sort(const uint32_t* offsets, uint32_t* indices, uint64_t nvox
     k_sort_long<0, 256><<<2048, 256, 0, s>>>(offsets, indices, queue, queue_cap, stats);
     k_sort_long<1, 1024><<<256, 1024, SORT_BIG * sizeof(uint32_t), s>>>(offsets, indices, queue, queue_cap, stats);
     k_sort_long<2, 1024><<<256, 1024, 0, s>>>(offsets, indices, queue, queue_cap, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_expand_records(const uint32_t* indices, uint64_t n_refs, const float4* tri_rec, uint32_t n_tris,
+                                 float4* ref_rec, uint64_t* stats, hipStream_t s) {
+    if (n_refs == 0) return hipSuccess;
+    k_expand_records<<<(unsigned)((n_refs + 255) / 256), 256, 0, s>>>(indices, n_refs, tri_rec, n_tris, ref_rec, stats);
+    return hipGetLastError();
+}
+
+hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint32_t* offsets, const GridParams& g,
+                            uint32_t n_tris, const uint32_t* ranges, uint32_t* face_bits, uint64_t face_words,
+                            hipStream_t s) {
+    // one lane per entry, rounded up so that every 64-bit word of the arrays (incl. the tail) is written
+    const uint64_t lanes = (face_words * 32 + 255) / 256 * 256;
+    if (lanes == 0) return hipSuccess;
+    k_face_bits<<<(unsigned)(lanes / 256), 256, 0, s>>>(indices, n_refs, offsets, g, n_tris, ranges, face_bits, face_words);
     return hipGetLastError();
 }
 

@@ -30,6 +30,16 @@ struct SceneDev {
     const uint32_t* offsets;
     const uint32_t* indices;
     uint32_t n_tris;
+    // ref_rec: one 48-byte record PER REFERENCE, in CSR order: v0, e1, e2 of triangle indices[j], the
+    // triangle id in the 10th dword, 2 pad dwords.  A voxel's list is then one contiguous run of records
+    // whose addresses do not depend on a loaded index: the index -> record dependent load of the
+    // traversal disappears and the next record can be prefetched while the current one is tested.
+    // Null when the context runs in indexed mode (HVRT_INLINE_RECORDS=0 or the array would not fit).
+    const float4* ref_rec;
+    // face_bits: 6 bit arrays of face_words u32 each, one bit per CSR entry j: entry j's triangle is also
+    // listed in the voxel's -x / +x / -y / +y / -z / +z neighbour (k_face_bits).  Always present.
+    const uint32_t* face_bits;
+    uint64_t face_words;
 };
 
 struct RenderArgs {
@@ -72,6 +82,11 @@ hipError_t launch_fill(const uint32_t* ranges, uint32_t n_tris, const GridParams
                        uint32_t* indices, hipStream_t s);
 hipError_t launch_sort(const uint32_t* offsets, uint32_t* indices, uint64_t nvox, uint32_t* long_queue,
                        uint64_t long_queue_capacity, uint64_t* stats, hipStream_t s);
+hipError_t launch_expand_records(const uint32_t* indices, uint64_t n_refs, const float4* tri_rec, uint32_t n_tris,
+                                 float4* ref_rec, uint64_t* stats, hipStream_t s);
+hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint32_t* offsets, const GridParams& g,
+                            uint32_t n_tris, const uint32_t* ranges /* null: search the neighbour lists */,
+                            uint32_t* face_bits, uint64_t face_words, hipStream_t s);
 hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s);
 hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* blocks x 6 + idx */,
                          uint64_t* partial_idx, int n_blocks, float* out6, hipStream_t s);

@@ -37,16 +37,30 @@ __device__ __forceinline__ V3 normalize(V3 v) {
 }
 
 // GeometryUtils.cpp:57-97 on a (v0, e1, e2) record.
+//
+// The reference divides first (inv_det = 1/det) and then tests u, v, u+v against [0,1] with FLT_EPSILON
+// slack.  Most tests fail those bounds by far, so the IEEE divide (11 instructions) is deferred: an
+// approximate reciprocal (v_rcp_f32, 1 ulp) gives u~, v~ within 2^-21 relative of the exact values, and a
+// test is rejected early only when u~ < -1e-3, u~ > 1.001, v~ < -1e-3 or u~ + v~ > 1.002 -- each of which
+// implies the reference's own rejection.  Everything else (including every NaN / inf case, which fails the
+// early compares) takes the exact path below, so hit / miss and t are bit-identical.
 __device__ __forceinline__ bool ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t_out) {
     V3 p = cross(d, e2);
     float det = dot(e1, p);
     if (det > -EPS && det < EPS) return false;
-    float inv = 1.0f / det;   // == (float)(1.0 / (double)det): double rounding is innocuous for 53 >= 2*24+2
     V3 s = sub(o, v0);
-    float u = inv * dot(s, p);
-    if ((u < 0.0f && fabsf(u) > EPS) || (u > 1.0f && fabsf(u - 1.0f) > EPS)) return false;
+    float su = dot(s, p);
+    const float r = __builtin_amdgcn_rcpf(det);
+    const float ua = su * r;
+    if (ua < -1e-3f || ua > 1.001f) return false;
     V3 q = cross(s, e1);
-    float v = inv * dot(d, q);
+    float sv = dot(d, q);
+    const float va = sv * r;
+    if (va < -1e-3f || ua + va > 1.002f) return false;
+    float inv = 1.0f / det;   // == (float)(1.0 / (double)det): double rounding is innocuous for 53 >= 2*24+2
+    float u = inv * su;
+    if ((u < 0.0f && fabsf(u) > EPS) || (u > 1.0f && fabsf(u - 1.0f) > EPS)) return false;
+    float v = inv * sv;
     if ((v < 0.0f && fabsf(v) > EPS) || (u + v > 1.0f && fabsf(u + v - 1.0f) > EPS)) return false;
     float t = inv * dot(e2, q);
     t_out = t;
@@ -59,47 +73,130 @@ struct TraceResult {
     uint32_t nv, nt;
 };
 
-// traverseVoxelGrid, OctreeLikeRayTracer.cpp:309-336.
+// traverseVoxelGrid, OctreeLikeRayTracer.cpp:309-336, in "while-while" form: every lane first steps
+// through empty voxels, so that the lanes of a wave reach their next occupied voxel together and the
+// triangle loop runs with most lanes active.  The visited voxel sequence, the tests and their order are
+// the reference's; only the bookkeeping differs:
+//   * the start voxel is in bounds (it is clamped) and every step moves one axis by its fixed +-1, so
+//     a ray visits at most nx+ny+nz-2 voxels: the reference's step cap (:318) can never fire and only
+//     the stepped axis needs a bounds check -- kept as "steps left before leaving the grid" counters;
+//   * the flat voxel index ix + nx*(iy + ny*iz) is updated incrementally (32-bit: Nvox < 2^32);
+//   * advanceToNextVoxel's nested strict '<' (:201-260) becomes three compares and selects with the same
+//     truth table (ties and NaNs fall to the else arms exactly as written there).
+template <bool COUNT, bool INLINE>
 __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d) {
     const GridParams& g = sc.g;
     TraceResult r;
     r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
 
     // initializeTraversal, :155-195 (start voxel = CLAMPED voxel of the origin, no entry test)
-    int ix = clampi(f2i((o.x - g.mnx) / g.vsx), 0, g.nx - 1);
-    int iy = clampi(f2i((o.y - g.mny) / g.vsy), 0, g.ny - 1);
-    int iz = clampi(f2i((o.z - g.mnz) / g.vsz), 0, g.nz - 1);
-    const int sx = (d.x > 0.0f) ? 1 : -1, sy = (d.y > 0.0f) ? 1 : -1, sz = (d.z > 0.0f) ? 1 : -1;
+    const int ix = clampi(f2i((o.x - g.mnx) / g.vsx), 0, g.nx - 1);
+    const int iy = clampi(f2i((o.y - g.mny) / g.vsy), 0, g.ny - 1);
+    const int iz = clampi(f2i((o.z - g.mnz) / g.vsz), 0, g.nz - 1);
+    const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;   // stepX = (dir > 0) ? 1 : -1
     const float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
-    float tmx = ((g.mnx + (float)((d.x > 0.0f) ? ix + 1 : ix) * g.vsx) - o.x) / d.x;
-    float tmy = ((g.mny + (float)((d.y > 0.0f) ? iy + 1 : iy) * g.vsy) - o.y) / d.y;
-    float tmz = ((g.mnz + (float)((d.z > 0.0f) ? iz + 1 : iz) * g.vsz) - o.z) / d.z;
+    float tmx = ((g.mnx + (float)(px ? ix + 1 : ix) * g.vsx) - o.x) / d.x;
+    float tmy = ((g.mny + (float)(py ? iy + 1 : iy) * g.vsy) - o.y) / d.y;
+    float tmz = ((g.mnz + (float)(pz ? iz + 1 : iz) * g.vsz) - o.z) / d.z;
+    int rx = px ? g.nx - 1 - ix : ix;      // steps left on each axis before the ray leaves the grid
+    int ry = py ? g.ny - 1 - iy : iy;
+    int rz = pz ? g.nz - 1 - iz : iz;
+    const uint32_t plane = (uint32_t)g.nx * (uint32_t)g.ny;
+    const uint32_t fsx = px ? 1u : 0xFFFFFFFFu;
+    const uint32_t fsy = py ? (uint32_t)g.nx : 0u - (uint32_t)g.nx;
+    const uint32_t fsz = pz ? plane : 0u - plane;
+    uint32_t f = (uint32_t)ix + (uint32_t)g.nx * (uint32_t)iy + plane * (uint32_t)iz;
 
-    const int max_steps = g.nx + g.ny + g.nz;   // :318
-    for (int it = 0; it < max_steps; ++it) {
-        if (!(ix >= 0 && ix < g.nx && iy >= 0 && iy < g.ny && iz >= 0 && iz < g.nz)) break;   // :321
-        // testVoxelTriangles, :267-295: the LAST list entry that hits wins
-        ++r.nv;
-        const uint64_t f = (uint64_t)ix + (uint64_t)g.nx * ((uint64_t)iy + (uint64_t)g.ny * (uint64_t)iz);
-        const uint32_t b0 = sc.offsets[f], b1 = sc.offsets[f + 1];
-        bool found = false;
-        for (uint32_t j = b0; j < b1; ++j) {
-            const uint32_t ti = sc.indices[j];
-            const float4 r0 = sc.tri_rec[3ull * ti], r1 = sc.tri_rec[3ull * ti + 1], r2 = sc.tri_rec[3ull * ti + 2];
-            float t;
-            ++r.nt;
-            if (ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, r2.x }, o, d, t)) {
-                r.tri = ti; r.t = t; found = true;
+    const uint32_t* __restrict__ offs = sc.offsets;
+    // face through which the current voxel was entered: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z neighbour
+    constexpr uint32_t NO_FACE = 6;
+    const uint32_t facex = px ? 0u : 1u, facey = py ? 2u : 3u, facez = pz ? 4u : 5u;
+    uint32_t face = NO_FACE;
+    uint32_t b0, b1;
+    bool alive = true;
+    if (COUNT) r.nv = 1;
+
+    // cxy picks the x-or-y candidate, c2 compares that candidate with z: the nested ifs of :204-259
+#define HVRT_ADVANCE()                                                          \
+    do {                                                                        \
+        const bool cxy = tmx < tmy;                                             \
+        const bool c2 = (cxy ? tmx : tmy) < tmz;                                \
+        const bool stx = cxy && c2, sty = !cxy && c2;                           \
+        tmx = stx ? tmx + tdx : tmx;                                            \
+        tmy = sty ? tmy + tdy : tmy;                                            \
+        tmz = c2 ? tmz : tmz + tdz;                                             \
+        rx -= stx ? 1 : 0; ry -= sty ? 1 : 0; rz -= c2 ? 0 : 1;                 \
+        f += c2 ? (cxy ? fsx : fsy) : fsz;                                      \
+        face = c2 ? (cxy ? facex : facey) : facez;                              \
+        alive = (rx | ry | rz) >= 0;                                            \
+    } while (0)
+#define HVRT_LOAD_VOXEL()                                                       \
+    do {                                                                        \
+        const uint32_t* pv = offs + f;                                          \
+        b0 = pv[0]; b1 = pv[1];                                                 \
+    } while (0)
+
+    HVRT_LOAD_VOXEL();
+    for (;;) {
+        // phase 1: walk through empty voxels (testVoxelTriangles on an unoccupied voxel does nothing)
+        while (alive && b0 == b1) {
+            HVRT_ADVANCE();
+            if (alive) {
+                HVRT_LOAD_VOXEL();
+                if (COUNT) ++r.nv;
             }
         }
-        if (found) break;   // :326-329
-        // advanceToNextVoxel, :201-260 -- literal nested strict '<' (ties / NaN fall to the else arms)
-        if (tmx < tmy) {
-            if (tmx < tmz) { ix += sx; tmx += tdx; } else { iz += sz; tmz += tdz; }
-        } else {
-            if (tmy < tmz) { iy += sy; tmy += tdy; } else { iz += sz; tmz += tdz; }
+        if (!alive) break;
+        // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
+        bool found = false;
+        {
+            // Entries that are also in the list of the voxel the ray just left were tested there one step
+            // ago with this very ray and missed (a hit would have ended it), so they are not tested again:
+            // sc.face_bits holds, per face, one bit per CSR entry ("also listed in that face neighbour"),
+            // read as a 32-entry window starting at b0.  Skipping never changes a result; it halves the
+            // records a lane has to fetch (the loop is bound by L1 data return, 40 B per lane and test).
+            const uint32_t n = b1 - b0;
+            for (uint32_t c = 0; c < n; c += 32) {
+                const uint32_t base = b0 + c;
+                uint32_t skip = 0;
+                if (face != NO_FACE) {
+                    const uint32_t* __restrict__ fb = sc.face_bits + (uint64_t)face * sc.face_words + (base >> 5);
+                    skip = __builtin_amdgcn_alignbit(fb[1], fb[0], base & 31u);
+                }
+                const uint32_t left = n - c;
+                uint32_t todo = ~skip & (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
+                while (todo) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const uint32_t j = base + k;
+                    float t;
+                    if (INLINE) {
+                        const float4* __restrict__ rec = sc.ref_rec + 3ull * j;
+                        const float4 c0 = rec[0], c1 = rec[1];
+                        const float2 c2 = *reinterpret_cast<const float2*>(rec + 2);
+                        if (ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, o, d, t)) {
+                            r.tri = __float_as_uint(c2.y); r.t = t; found = true;
+                        }
+                    } else {
+                        const uint32_t ti = sc.indices[j];
+                        const float4 r0 = sc.tri_rec[3ull * ti], r1 = sc.tri_rec[3ull * ti + 1];
+                        const float e2z = reinterpret_cast<const float*>(sc.tri_rec + 3ull * ti + 2)[0];
+                        if (ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, e2z }, o, d, t)) {
+                            r.tri = ti; r.t = t; found = true;
+                        }
+                    }
+                }
+            }
         }
+        if (COUNT) r.nt += b1 - b0;
+        if (found) break;   // :326-329
+        HVRT_ADVANCE();
+        if (!alive) break;
+        HVRT_LOAD_VOXEL();
+        if (COUNT) ++r.nv;
     }
+#undef HVRT_ADVANCE
+#undef HVRT_LOAD_VOXEL
     return r;
 }
 
@@ -137,6 +234,7 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 
 // Persistent threads: every wave loops pulling 8x8 pixel tiles until the queue is empty; the
 // exit condition (tile >= n_tiles) is reached by every wave whatever the grid size.
+template <bool COUNT, bool INLINE>
 __global__ __launch_bounds__(256) void k_render(SceneDev sc, RenderArgs ra) {
     const int lane = threadIdx.x & 63;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
@@ -172,11 +270,11 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, RenderArgs ra) {
             const float v = ((float)y + jy) / (float)ra.height;
             // generateRay, :361-364
             const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
-            const TraceResult r = trace_ray(sc, org, d);
+            const TraceResult r = trace_ray<COUNT, INLINE>(sc, org, d);
             const V3 c = shade(sc, r, org, v);
             if (ra.spp == 1) acc = c; else acc = add(acc, c);
             if (s == 0) { hit0 = r.tri; t0 = r.t; }
-            tot_nv += r.nv; tot_nt += r.nt;
+            if (COUNT) { tot_nv += r.nv; tot_nt += r.nt; }
         }
         if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
         const size_t p = (size_t)lr * ra.width + x;
@@ -184,7 +282,7 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, RenderArgs ra) {
         if (ra.hit_id) ra.hit_id[p] = hit0;
         if (ra.t) ra.t[p] = t0;
     }
-    if (ra.counters) {
+    if (COUNT && ra.counters) {
         tot_nv = wave_sum64(tot_nv);
         tot_nt = wave_sum64(tot_nt);
         if (lane == 0) {
@@ -195,6 +293,7 @@ __global__ __launch_bounds__(256) void k_render(SceneDev sc, RenderArgs ra) {
 }
 
 // traceRay batch: one lane per ray, RayHit records out (OctreeLikeRayTracer.cpp:124-126, :283-288).
+template <bool INLINE>
 __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const float* __restrict__ origins,
                                                const float* __restrict__ dirs, uint32_t n,
                                                hvrt_hit* __restrict__ out, unsigned long long* counters) {
@@ -203,7 +302,7 @@ __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const float* __restr
     if (i < n) {
         const V3 o = { origins[3ull * i], origins[3ull * i + 1], origins[3ull * i + 2] };
         const V3 d = { dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2] };
-        const TraceResult r = trace_ray(sc, o, d);
+        const TraceResult r = trace_ray<true, INLINE>(sc, o, d);
         hvrt_hit h;
         h.hit = r.tri != HVRT_MISS;
         h.t = r.t;
@@ -255,14 +354,17 @@ hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hi
     uint64_t blocks = (n_tiles + 3) / 4;
     const uint64_t cap = (uint64_t)n_cus * 8;   // 8 x 256-thread workgroups fill a CU's 32 wave slots
     if (blocks > cap) blocks = cap;
-    k_render<<<(unsigned)blocks, 256, 0, s>>>(sc, ra);
+    const bool il = sc.ref_rec != nullptr;
+    if (ra.counters) { if (il) k_render<true, true><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); else k_render<true, false><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); }
+    else             { if (il) k_render<false, true><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); else k_render<false, false><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); }
     return hipGetLastError();
 }
 
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n, hvrt_hit* out,
                         unsigned long long* counters, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    k_trace<<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+    if (sc.ref_rec) k_trace<true><<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+    else k_trace<false><<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
     return hipGetLastError();
 }
 

@@ -32,7 +32,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.CameraFrame) == 48
     assert capi.HIT_DTYPE.itemsize == 52        # RayHit is 52 bytes in the reference
     assert C.sizeof(capi.GridInfo) == 3 * 4 + 9 * 4 + 3 * 8 + 2 * 4
-    assert C.sizeof(capi.Timings) == 7 * 4
+    assert C.sizeof(capi.Timings) == 8 * 4
 
 
 def test_create_without_gpu_fails_loudly_or_works():

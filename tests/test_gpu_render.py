@@ -212,3 +212,46 @@ def test_config2_full_size_render_rows(ctx):
     v = (np.arange(H, dtype=np.float32) / np.float32(H))[:, None]
     bg = np.float32(0.5) + np.float32(0.3) * v
     assert np.array_equal(np.broadcast_to(bg, (H, W))[~m], rgb[..., 0][~m])
+
+
+@pytest.mark.parametrize("name", ["sphere_16", "slivers", "skewed_long_lists"])
+def test_render_from_an_ingested_cpu_grid(ctx, name):
+    """IRayTracer's constructor path: the CSR comes from the CPU (hvrt_set_grid_csr); the skip bits are
+    then derived by searching the neighbour lists instead of from the builder's ranges."""
+    gen, dims, (W, H) = SCENES[name]
+    tris = gen()
+    sc, mn, mx, vs = oracle.build_scene(tris, *dims)
+    ctx.set_mesh(tris)
+    ctx.set_grid_csr(*dims, mn, mx, vs, sc.offsets, sc.indices)
+    for view in ("front", "top"):
+        pos, la, up, fov, asp = capi.default_camera(mn, mx, view)
+        fr = capi.make_camera_frame(pos, la, up, fov, asp)
+        assert_frames_equal(ctx.render(fr, W, H), sc.render(fr, W, H, threads=8))
+
+
+def test_ingested_grid_with_unsorted_or_foreign_lists(ctx):
+    """A CSR that is not the AABB-range CSR (lists shuffled, some entries dropped): results must still be the
+    reference algorithm's on THAT grid (last list entry that hits wins), skip bits or not."""
+    tris = meshgen.cube_sphere(14)
+    sc, mn, mx, vs = oracle.build_scene(tris, 20, 20, 20)
+    rng = np.random.default_rng(8)
+    off, idx = sc.offsets.astype(np.int64), sc.indices.copy()
+    new_idx, new_off = [], [0]
+    for v in range(off.size - 1):
+        seg = idx[off[v]:off[v + 1]]
+        seg = seg[rng.random(seg.size) < 0.8]
+        rng.shuffle(seg)
+        new_idx.append(seg)
+        new_off.append(new_off[-1] + seg.size)
+    nidx = np.concatenate(new_idx).astype(np.uint32)
+    noff = np.asarray(new_off, np.uint32)
+    sc2 = oracle.OracleScene(tris, 20, 20, 20, mn, vs, noff, nidx)
+    ctx.set_mesh(tris)
+    ctx.set_grid_csr(20, 20, 20, mn, mx, vs, noff, nidx)
+    pos, la, up, fov, asp = capi.default_camera(mn, mx)
+    fr = capi.make_camera_frame(pos, la, up, fov, asp)
+    assert_frames_equal(ctx.render(fr, 200, 150), sc2.render(fr, 200, 150, threads=8))
+    bad = nidx.copy()
+    bad[5] = tris.shape[0] + 7
+    with pytest.raises(capi.HvrtError):
+        ctx.set_grid_csr(20, 20, 20, mn, mx, vs, noff, bad)
