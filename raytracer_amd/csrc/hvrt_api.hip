@@ -53,6 +53,8 @@ struct hvrt_ctx {
     uint64_t* block_sums = nullptr; uint64_t block_sums_capacity = 0;
     uint64_t* stats = nullptr;     // 8 x u64
     uint32_t* long_queue = nullptr; uint64_t long_queue_capacity = 0;
+    uint32_t* fill_scratch = nullptr; uint64_t fill_scratch_capacity = 0;  // unsorted ids | voxel of each entry
+    const uint32_t* vox_of = nullptr;  // valid between fill and the end of hvrt_build_grid
     float* bounds_v = nullptr; uint64_t* bounds_i = nullptr; float* bounds_out = nullptr;
 
     // render scratch
@@ -160,7 +162,7 @@ int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate) {
     c->face_words = (c->n_refs + 63) / 64 * 2 + 2;
     if (int r = ensure<uint32_t>(c, c->face_bits, c->face_bits_capacity, 6 * c->face_words)) return r;
     HIP_TRY(c, launch_face_bits(c->indices, c->n_refs, offsets_of(c), c->g, c->n_tris, validate ? nullptr : c->ranges,
-                                c->face_bits, c->face_words, s));
+                                validate ? nullptr : c->vox_of, c->face_bits, c->face_words, s));
     if (c->n_refs == 0) return HVRT_OK;
     const bool want = c->inline_records;
     if (want) {
@@ -234,7 +236,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->ranges, c->block_sums, c->stats, c->long_queue,
+    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -373,15 +375,21 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     if (total > 0xFFFFFFFFull)
         return fail(c, HVRT_ERR_OVERFLOW, "build_grid: %llu triangle references exceed the u32 CSR", (unsigned long long)total);
     if (int r = ensure<uint32_t>(c, c->indices, c->indices_capacity, total)) return r;
-    if (int r = ensure<uint32_t>(c, c->long_queue, c->long_queue_capacity, total / 33 + 1)) return r;
+    if (int r = ensure<uint32_t>(c, c->long_queue, c->long_queue_capacity, total / 64 + 1)) return r;
+    if (int r = ensure<uint32_t>(c, c->fill_scratch, c->fill_scratch_capacity, 2 * total)) return r;
+    uint32_t* unsorted = c->fill_scratch;
+    uint32_t* vox_of = c->fill_scratch + total;
 
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), c->indices, s));
+    HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, s));
     HIP_TRY(c, hipEventRecord(c->ev[4], s));
-    HIP_TRY(c, launch_sort(offsets_of(c), c->indices, nvox, c->long_queue, c->long_queue_capacity, c->stats, s));
+    HIP_TRY(c, launch_sort(offsets_of(c), unsorted, vox_of, total, c->indices, c->long_queue, c->long_queue_capacity, c->stats, s));
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
     c->n_refs = total;
-    if (int r = make_ref_records(c, s, false)) return r;
+    c->vox_of = vox_of;
+    const int rr = make_ref_records(c, s, false);
+    c->vox_of = nullptr;
+    if (rr) return rr;
     HIP_TRY(c, hipEventRecord(c->ev[8], s));
     HIP_TRY(c, hipStreamSynchronize(s));
 

@@ -58,17 +58,18 @@ __global__ __launch_bounds__(256) void k_prepare_records(const float4* __restric
 constexpr uint32_t SMALL_VOL = 32;  // ranges up to this many voxels are walked by the owning lane
 
 template <bool FILL>
-__device__ __forceinline__ void touch(uint32_t* cnt, uint32_t* indices, uint64_t f, uint32_t t) {
+__device__ __forceinline__ void touch(uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, uint64_t f, uint32_t t) {
     if (FILL) {
         uint32_t p = atomicAdd(&cnt[f], 1u);
         indices[p] = t;
+        vox_of[p] = (uint32_t)f;
     } else {
         atomicAdd(&cnt[f], 1u);
     }
 }
 
 template <bool FILL>
-__device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, uint32_t* indices, uint32_t t,
+__device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, uint32_t t,
                                            bool valid, int lx, int ly, int lz, int hx, int hy, int hz) {
     const uint32_t dx = valid ? (uint32_t)(hx - lx + 1) : 0u;
     const uint32_t dy = valid ? (uint32_t)(hy - ly + 1) : 0u;
@@ -78,7 +79,7 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
     if (valid && !big) {
         for (int iz = lz; iz <= hz; ++iz)
             for (int iy = ly; iy <= hy; ++iy)
-                for (int ix = lx; ix <= hx; ++ix) touch<FILL>(cnt, indices, flat_index(g, ix, iy, iz), t);
+                for (int ix = lx; ix <= hx; ++ix) touch<FILL>(cnt, indices, vox_of, flat_index(g, ix, iy, iz), t);
     }
     // Triangles that span many voxels: the whole wave walks each one (every lane reaches here).
     unsigned long long m = __ballot(big);
@@ -95,7 +96,7 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
             const uint32_t iz = (uint32_t)(i / plane);
             const uint32_t r = (uint32_t)(i - (uint64_t)iz * plane);
             const uint32_t iy = r / bdx, ix = r - iy * bdx;
-            touch<FILL>(cnt, indices, flat_index(g, blx + (int)ix, bly + (int)iy, blz + (int)iz), bt);
+            touch<FILL>(cnt, indices, vox_of, flat_index(g, blx + (int)ix, bly + (int)iy, blz + (int)iz), bt);
         }
     }
 }
@@ -123,11 +124,12 @@ __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, u
         ranges[3ull * t + 2] = (uint32_t)lz | ((uint32_t)hz << 16);
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
-    walk_range<false>(g, cnt, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
+    walk_range<false>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
 }
 
 __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ ranges, uint32_t T, GridParams g,
-                                              uint32_t* __restrict__ cnt, uint32_t* __restrict__ indices) {
+                                              uint32_t* __restrict__ cnt, uint32_t* __restrict__ indices,
+                                              uint32_t* __restrict__ vox_of) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool valid = t < T;
     int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ range
         lz = (int)(rz & 0xFFFFu); hz = (int)(rz >> 16);
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
-    walk_range<true>(g, cnt, indices, t, nonempty, lx, ly, lz, hx, hy, hz);
+    walk_range<true>(g, cnt, indices, vox_of, t, nonempty, lx, ly, lz, hx, hy, hz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -250,34 +252,35 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint4* __restrict__ cnt4, co
 // ------------------------------------------------------------------------------------------
 // per-voxel ascending order
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t SORT_SMALL = 32;      // insertion sort by the owning lane up to here
+constexpr uint32_t SORT_SMALL = 96;      // lists up to here are ordered by rank counting, one lane per entry
 constexpr uint32_t SORT_MID = 4096;      // static-LDS bitonic (16 KiB)
 constexpr uint32_t SORT_BIG = 32768;     // dynamic-LDS bitonic (128 KiB of the CU's 160 KiB)
 
-__global__ __launch_bounds__(256) void k_sort_small(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ indices,
-                                                    uint64_t nvox, uint32_t* __restrict__ queue, uint64_t queue_cap,
-                                                    uint64_t* __restrict__ stats) {
-    const uint64_t v = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (v >= nvox) return;
-    const uint32_t b0 = offsets[v], b1 = offsets[v + 1];
+// One lane per CSR entry: the entry's final position inside its voxel's list is the number of entries
+// of that list with a smaller triangle id (ids are unique within a list).  Lanes of one voxel read the same
+// few cache lines, the work per lane is the list length, and the result is written out of place -- no
+// per-voxel pass over the (mostly empty) grid and no serial insertion loops.  Longer lists are copied
+// through unchanged and queued once (by their first entry) for the bitonic kernels.
+__global__ __launch_bounds__(256) void k_rank_sort(const uint32_t* __restrict__ unsorted, const uint32_t* __restrict__ vox_of,
+                                                   const uint32_t* __restrict__ offsets, uint64_t n_refs,
+                                                   uint32_t* __restrict__ sorted, uint32_t* __restrict__ queue,
+                                                   uint64_t queue_cap, uint64_t* __restrict__ stats) {
+    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (j >= n_refs) return;
+    const uint32_t v = vox_of[j];
+    const uint32_t b0 = offsets[v], b1 = offsets[(uint64_t)v + 1];
+    const uint32_t key = unsorted[j];
     const uint32_t len = b1 - b0;
-    if (len <= 1) return;
     if (len <= SORT_SMALL) {
-        uint32_t* a = indices + b0;
-        for (uint32_t i = 1; i < len; ++i) {
-            uint32_t key = a[i];
-            uint32_t j = i;
-            while (j > 0) {
-                uint32_t prev = a[j - 1];
-                if (prev <= key) break;
-                a[j] = prev;
-                --j;
-            }
-            if (j != i) a[j] = key;
-        }
+        uint32_t rank = 0;
+        for (uint32_t q = b0; q < b1; ++q) rank += unsorted[q] < key;
+        sorted[b0 + rank] = key;
     } else {
-        unsigned long long slot = atomicAdd((unsigned long long*)&stats[3], 1ull);
-        if (slot < queue_cap) queue[slot] = (uint32_t)v;
+        sorted[j] = key;
+        if ((uint32_t)j == b0) {
+            unsigned long long slot = atomicAdd((unsigned long long*)&stats[3], 1ull);
+            if (slot < queue_cap) queue[slot] = v;
+        }
     }
 }
 
@@ -307,7 +310,7 @@ __device__ __forceinline__ void bitonic_any_n(Ptr a, uint32_t n, uint32_t tid, u
     }
 }
 
-// TIER 0: 33..4096 (static LDS), 1: 4097..32768 (dynamic LDS), 2: above (in global memory)
+// TIER 0: SORT_SMALL+1..4096 (static LDS), 1: 4097..32768 (dynamic LDS), 2: above (in global memory)
 template <int TIER, int NT>
 __global__ __launch_bounds__(NT) void k_sort_long(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ indices,
                                                   const uint32_t* __restrict__ queue, uint64_t queue_cap,
@@ -374,16 +377,17 @@ __device__ __forceinline__ bool list_contains(const uint32_t* __restrict__ indic
 
 __global__ __launch_bounds__(256) void k_face_bits(const uint32_t* __restrict__ indices, uint64_t n_refs,
                                                    const uint32_t* __restrict__ offsets, GridParams g, uint32_t n_tris,
-                                                   const uint32_t* __restrict__ ranges,
+                                                   const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vox_of,
                                                    uint32_t* __restrict__ face_bits, uint64_t face_words) {
     const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     uint32_t mask = 0;
     if (j < n_refs) {
         const uint32_t ti = indices[j];
         if (ti < n_tris) {
-            // voxel of entry j: the last v with offsets[v] <= j
+            // voxel of entry j: recorded by the fill, else the last v with offsets[v] <= j
             uint64_t lo = 0, hi = g.nvox;            // invariant: offsets[lo] <= j < offsets[hi]
-            while (hi - lo > 1) {
+            if (vox_of) lo = vox_of[j];
+            else while (hi - lo > 1) {
                 const uint64_t m = lo + ((hi - lo) >> 1);
                 if (offsets[m] <= (uint32_t)j) lo = m; else hi = m;
             }
@@ -548,14 +552,14 @@ hipError_t launch_scan_apply(uint32_t* cnt, uint64_t n_chunks, const uint64_t* b
 }
 
 hipError_t launch_fill(const uint32_t* ranges, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* indices,
-                       hipStream_t s) {
+                       uint32_t* vox_of, hipStream_t s) {
     if (T == 0) return hipSuccess;
-    k_fill<<<(T + 255) / 256, 256, 0, s>>>(ranges, T, g, cnt, indices);
+    k_fill<<<(T + 255) / 256, 256, 0, s>>>(ranges, T, g, cnt, indices, vox_of);
     return hipGetLastError();
 }
 
-hipError_t launch_sort(const uint32_t* offsets, uint32_t* indices, uint64_t nvox, uint32_t* queue, uint64_t queue_cap,
-                       uint64_t* stats, hipStream_t s) {
+hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, uint64_t n_refs,
+                       uint32_t* indices, uint32_t* queue, uint64_t queue_cap, uint64_t* stats, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_sort_long<1, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -563,7 +567,8 @@ hipError_t launch_sort(const uint32_t* offsets, uint32_t* indices, uint64_t nvox
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    k_sort_small<<<(unsigned)((nvox + 255) / 256), 256, 0, s>>>(offsets, indices, nvox, queue, queue_cap, stats);
+    if (n_refs == 0) return hipSuccess;
+    k_rank_sort<<<(unsigned)((n_refs + 255) / 256), 256, 0, s>>>(unsorted, vox_of, offsets, n_refs, indices, queue, queue_cap, stats);
     k_sort_long<0, 256><<<2048, 256, 0, s>>>(offsets, indices, queue, queue_cap, stats);
     k_sort_long<1, 1024><<<256, 1024, SORT_BIG * sizeof(uint32_t), s>>>(offsets, indices, queue, queue_cap, stats);
     k_sort_long<2, 1024><<<256, 1024, 0, s>>>(offsets, indices, queue, queue_cap, stats);
@@ -578,12 +583,12 @@ hipError_t launch_expand_records(const uint32_t* indices, uint64_t n_refs, const
 }
 
 hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint32_t* offsets, const GridParams& g,
-                            uint32_t n_tris, const uint32_t* ranges, uint32_t* face_bits, uint64_t face_words,
-                            hipStream_t s) {
+                            uint32_t n_tris, const uint32_t* ranges, const uint32_t* vox_of, uint32_t* face_bits,
+                            uint64_t face_words, hipStream_t s) {
     // one lane per entry, rounded up so that every 64-bit word of the arrays (incl. the tail) is written
     const uint64_t lanes = (face_words * 32 + 255) / 256 * 256;
     if (lanes == 0) return hipSuccess;
-    k_face_bits<<<(unsigned)(lanes / 256), 256, 0, s>>>(indices, n_refs, offsets, g, n_tris, ranges, face_bits, face_words);
+    k_face_bits<<<(unsigned)(lanes / 256), 256, 0, s>>>(indices, n_refs, offsets, g, n_tris, ranges, vox_of, face_bits, face_words);
     return hipGetLastError();
 }
 

@@ -79,13 +79,15 @@ hipError_t launch_scan_reduce(const uint32_t* cnt, uint64_t n_chunks, uint64_t* 
 hipError_t launch_scan_sums(uint64_t* block_sums, uint64_t n_chunks, uint64_t* stats, hipStream_t s);
 hipError_t launch_scan_apply(uint32_t* cnt, uint64_t n_chunks, const uint64_t* block_sums, hipStream_t s);
 hipError_t launch_fill(const uint32_t* ranges, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
-                       uint32_t* indices, hipStream_t s);
-hipError_t launch_sort(const uint32_t* offsets, uint32_t* indices, uint64_t nvox, uint32_t* long_queue,
-                       uint64_t long_queue_capacity, uint64_t* stats, hipStream_t s);
+                       uint32_t* indices_unsorted, uint32_t* vox_of, hipStream_t s);
+hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, uint64_t n_refs,
+                       uint32_t* indices, uint32_t* long_queue, uint64_t long_queue_capacity, uint64_t* stats,
+                       hipStream_t s);
 hipError_t launch_expand_records(const uint32_t* indices, uint64_t n_refs, const float4* tri_rec, uint32_t n_tris,
                                  float4* ref_rec, uint64_t* stats, hipStream_t s);
 hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint32_t* offsets, const GridParams& g,
                             uint32_t n_tris, const uint32_t* ranges /* null: search the neighbour lists */,
+                            const uint32_t* vox_of /* null: search the offsets */,
                             uint32_t* face_bits, uint64_t face_words, hipStream_t s);
 hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s);
 hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* blocks x 6 + idx */,

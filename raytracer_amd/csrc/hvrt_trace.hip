@@ -172,10 +172,11 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                     float t;
                     if (INLINE) {
                         const float4* __restrict__ rec = sc.ref_rec + 3ull * j;
+                        // 36 of the record's 48 bytes; the triangle id (10th dword) is fetched only on a hit
                         const float4 c0 = rec[0], c1 = rec[1];
-                        const float2 c2 = *reinterpret_cast<const float2*>(rec + 2);
-                        if (ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, o, d, t)) {
-                            r.tri = __float_as_uint(c2.y); r.t = t; found = true;
+                        const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
+                        if (ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, t)) {
+                            r.tri = __float_as_uint(reinterpret_cast<const float*>(rec + 2)[1]); r.t = t; found = true;
                         }
                     } else {
                         const uint32_t ti = sc.indices[j];
