@@ -356,7 +356,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
 
     if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
     if (int r = ensure<uint32_t>(c, c->ranges, c->ranges_capacity, (uint64_t)c->n_tris * 3)) return r;
-    if (int r = ensure<uint64_t>(c, c->block_sums, c->block_sums_capacity, n_chunks)) return r;
+    if (int r = ensure<uint64_t>(c, c->block_sums, c->block_sums_capacity, 2 * n_chunks)) return r;
 
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));

@@ -68,6 +68,38 @@ __device__ __forceinline__ void touch(uint32_t* cnt, uint32_t* indices, uint32_t
     }
 }
 
+// One voxel per lane, touched with wave-aggregated atomics: mesh order is spatial order more often than not,
+// so neighbouring lanes tend to name the same voxel.  Each run of adjacent active lanes with equal voxel
+// issues ONE atomicAdd of the run length (its first lane), and in the fill the others take consecutive
+// slots behind it.  A dense cluster of small triangles (thousands per voxel) otherwise serialises on a
+// handful of L2 atomic units.  Every lane of the wave must call this (ballot / shuffle inside).
+template <bool FILL>
+__device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, bool act, uint32_t f, uint32_t t) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long S = __ballot(act);
+    if (S == 0) return;
+    const uint32_t fprev = __shfl_up(f, 1);
+    const bool prev_act = lane > 0 && ((S >> (lane - 1)) & 1ull);
+    const unsigned long long H = __ballot(act && (!prev_act || fprev != f));
+    // my run's first lane: the highest head at or below me
+    const unsigned long long below = H & (~0ull >> (63 - lane));
+    const int hl = act ? 63 - __builtin_clzll(below) : lane;
+    uint32_t base = 0;
+    if (act && hl == lane) {
+        const unsigned long long stop = (H | ~S) & ~(~0ull >> (63 - lane));   // next head or inactive lane above me
+        const uint32_t len = (uint32_t)((stop ? __builtin_ctzll(stop) : 64) - lane);
+        base = atomicAdd(&cnt[f], len);
+    }
+    if (FILL) {
+        base = __shfl(base, hl);
+        if (act) {
+            const uint32_t p = base + (uint32_t)(lane - hl);
+            indices[p] = t;
+            vox_of[p] = f;
+        }
+    }
+}
+
 template <bool FILL>
 __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, uint32_t t,
                                            bool valid, int lx, int ly, int lz, int hx, int hy, int hz) {
@@ -76,10 +108,18 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
     const uint32_t dz = valid ? (uint32_t)(hz - lz + 1) : 0u;
     const uint64_t vol = (uint64_t)dx * dy * dz;
     const bool big = vol > SMALL_VOL;
-    if (valid && !big) {
-        for (int iz = lz; iz <= hz; ++iz)
-            for (int iy = ly; iy <= hy; ++iy)
-                for (int ix = lx; ix <= hx; ++ix) touch<FILL>(cnt, indices, vox_of, flat_index(g, ix, iy, iz), t);
+    // Small ranges: the wave steps through "k-th voxel of my range" together (x fastest, like the
+    // reference's loops) until the longest range of the wave is done.
+    {
+        const bool small = valid && !big;
+        int ix = lx, iy = ly, iz = lz;
+        bool act = small;
+        while (__ballot(act)) {
+            touch_runs<FILL>(cnt, indices, vox_of, act, (uint32_t)flat_index(g, ix, iy, iz), t);
+            if (act) {
+                if (++ix > hx) { ix = lx; if (++iy > hy) { iy = ly; if (++iz > hz) act = false; } }
+            }
+        }
     }
     // Triangles that span many voxels: the whole wave walks each one (every lane reaches here).
     unsigned long long m = __ballot(big);
@@ -195,8 +235,9 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint4* __restrict__ c
         uint32_t tm = s_mx[0];
         for (int i = 1; i < 4; ++i) tm = s_mx[i] > tm ? s_mx[i] : tm;
         block_sums[c] = ts;
-        if (to) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)to);
-        if (tm) atomicMax((unsigned long long*)&stats[2], (unsigned long long)tm);
+        // occupied count and longest list of the chunk ride along (no same-address atomics: a quarter of a
+        // million of them serialised in L2 and cost four times the 4-GB read itself)
+        block_sums[gridDim.x + c] = to | ((uint64_t)tm << 32);
     }
 }
 
@@ -207,8 +248,21 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ block
     const uint64_t per = (n + 1023) / 1024;
     const uint64_t b = threadIdx.x * per;
     const uint64_t e = b + per < n ? b + per : n;
-    uint64_t sum = 0;
-    for (uint64_t i = b; i < e; ++i) sum += block_sums[i];
+    uint64_t sum = 0, occ = 0;
+    uint32_t mx = 0;
+    for (uint64_t i = b; i < e; ++i) {
+        sum += block_sums[i];
+        const uint64_t aux = block_sums[n + i];
+        occ += aux & 0xFFFFFFFFull;
+        const uint32_t m = (uint32_t)(aux >> 32);
+        mx = m > mx ? m : mx;
+    }
+    occ = wave_sum64(occ);
+    mx = wave_max32(mx);
+    if ((threadIdx.x & 63) == 0) {
+        if (occ) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)occ);
+        if (mx) atomicMax((unsigned long long*)&stats[2], (unsigned long long)mx);
+    }
     s[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
@@ -222,30 +276,39 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ block
     if (threadIdx.x == 1023) stats[0] = s[1023];
 }
 
-// phase C: per-chunk exclusive scan, in place
+// phase C: per-chunk exclusive scan, in place.  Each wave owns 1024 consecutive counters and walks them in
+// four fully coalesced 1-KiB rows (lane i holds counters 4i..4i+3 of the row), scanning each row with wave
+// shuffles and carrying the row total forward; the four wave totals meet once in LDS.
 __global__ __launch_bounds__(256) void k_scan_apply(uint4* __restrict__ cnt4, const uint64_t* __restrict__ block_sums) {
     const uint64_t c = blockIdx.x;
-    uint4* p = cnt4 + c * (SCAN_CHUNK / 4) + threadIdx.x * 4;
-    uint4 v[4];
-    uint32_t tot = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[j] = p[j]; tot += v[j].x + v[j].y + v[j].z + v[j].w; }
-    __shared__ uint32_t s_w[4];
-    uint32_t inc = wave_inclusive_scan(tot);
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 63) s_w[w] = inc;
+    uint4* p = cnt4 + c * (SCAN_CHUNK / 4) + w * 256 + lane;
+    uint4 v[4];
+    uint32_t excl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = p[k * 64];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t tot = v[k].x + v[k].y + v[k].z + v[k].w;
+        const uint32_t inc = wave_inclusive_scan(tot);
+        excl[k] = carry + inc - tot;
+        carry += __shfl(inc, 63);
+    }
+    __shared__ uint32_t s_w[4];
+    if (lane == 0) s_w[w] = carry;
     __syncthreads();
     uint32_t base = (uint32_t)block_sums[c];
     for (int i = 0; i < w; ++i) base += s_w[i];
-    uint32_t run = base + inc - tot;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int k = 0; k < 4; ++k) {
+        uint32_t run = base + excl[k];
         uint4 o;
-        o.x = run; run += v[j].x;
-        o.y = run; run += v[j].y;
-        o.z = run; run += v[j].z;
-        o.w = run; run += v[j].w;
-        p[j] = o;
+        o.x = run; run += v[k].x;
+        o.y = run; run += v[k].y;
+        o.z = run; run += v[k].z;
+        o.w = run;
+        p[k * 64] = o;
     }
 }
 
