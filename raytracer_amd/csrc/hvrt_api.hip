@@ -45,6 +45,8 @@ struct hvrt_ctx {
     uint32_t* face_bits = nullptr; // 6 x face_words u32, see SceneDev
     uint64_t face_bits_capacity = 0;
     uint64_t face_words = 0;
+    uint8_t* dist = nullptr;       // per-voxel empty-space distance, see SceneDev
+    uint64_t dist_capacity = 0;
     uint64_t n_refs = 0, n_occupied = 0;
     uint32_t max_list = 0;
 
@@ -144,6 +146,7 @@ SceneDev scene_of(const hvrt_ctx* c) {
     s.ref_rec = c->ref_rec_valid ? c->ref_rec : nullptr;
     s.face_bits = c->face_bits;
     s.face_words = c->face_words;
+    s.dist = c->dist;
     return s;
 }
 
@@ -157,6 +160,8 @@ int require_scene(hvrt_ctx* c) {
 // indexed traversal when switched off or when the array does not fit in device memory.
 int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate) {
     c->ref_rec_valid = false;
+    if (int r = ensure<uint8_t>(c, c->dist, c->dist_capacity, c->g.nvox + 64)) return r;
+    HIP_TRY(c, launch_distance_field(offsets_of(c), c->g, c->dist, s));
     // face bits: one bit per entry and face, padded by two words so that a 32-entry window read at the
     // last entry stays inside the array
     c->face_words = (c->n_refs + 63) / 64 * 2 + 2;
@@ -236,7 +241,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
-    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
+    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);

@@ -507,6 +507,100 @@ __global__ __launch_bounds__(256) void k_csr_stats(const uint32_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// empty-space distance field (SceneDev::dist)
+// ------------------------------------------------------------------------------------------
+// dist[f] = min(255, city-block distance in voxels from voxel f to the nearest occupied voxel); 0 = occupied.
+// The traversal moves one face per step, so from a voxel with dist D the next D-1 voxels of ANY ray are
+// empty and need not be looked at.  The city-block distance separates per axis:
+//   D1(x,y,z) = min_x' |x-x'| + [occupied(x',y,z) ? 0 : inf],  D2 = min_y' |y-y'| + D1(x,y',z),  D = min_z' ... D2
+// and each 1-D pass is a forward and a backward sweep.  All values saturate at 255 (a saturated value only
+// shortens a skip).
+
+// x pass: one wave per x line, 64 voxels per step; occupancy comes straight from the CSR offsets, and the
+// distance to the previous / next occupied voxel of the line from the wave's ballot word.
+__global__ __launch_bounds__(256) void k_dist_x(const uint32_t* __restrict__ offsets, uint8_t* __restrict__ dist,
+                                                uint32_t nx, uint64_t n_lines) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * 256u) >> 6;
+    for (uint64_t line = wave0; line < n_lines; line += n_waves) {
+        const uint32_t* o = offsets + line * nx;
+        uint8_t* p = dist + line * nx;
+        uint32_t carry = 255;   // distance from the voxel before this chunk back to the last occupied one
+        for (uint32_t c = 0; c < nx; c += 64) {
+            const uint32_t i = c + lane;
+            const bool in = i < nx;
+            const bool occ = in && o[i + 1] != o[i];
+            const unsigned long long m = __ballot(occ);
+            const unsigned long long mm = m & (~0ull >> (63 - lane));
+            uint32_t d = mm ? (uint32_t)(lane - (63 - __builtin_clzll(mm))) : carry + (uint32_t)lane + 1u;
+            d = d > 255u ? 255u : d;
+            if (in) p[i] = (uint8_t)d;
+            carry = m ? (uint32_t)__builtin_clzll(m) : carry + 64u;
+            carry = carry > 255u ? 255u : carry;
+        }
+        carry = 255;            // distance from the voxel after this chunk on to the next occupied one
+        const uint32_t last = (nx - 1) / 64 * 64;
+        for (uint32_t c = last;; c -= 64) {
+            const uint32_t i = c + lane;
+            const bool in = i < nx;
+            const uint32_t fw = in ? p[i] : 255u;
+            const unsigned long long m = __ballot(in && fw == 0);
+            const unsigned long long mm = m & (~0ull << lane);
+            uint32_t d = mm ? (uint32_t)(__builtin_ctzll(mm) - lane) : carry + (uint32_t)(64 - lane);
+            d = d < fw ? d : fw;
+            if (in && d != fw) p[i] = (uint8_t)d;
+            carry = m ? (uint32_t)__builtin_ctzll(m) : carry + 64u;
+            carry = carry > 255u ? 255u : carry;
+            if (c == 0) break;
+        }
+    }
+}
+
+// y and z passes: one lane per line (lines are indexed so that neighbouring lanes are neighbouring x: every
+// access of a wave is one 64-byte run); eight loads in flight per lane.
+__global__ __launch_bounds__(256) void k_dist_sweep(uint8_t* __restrict__ dist, uint64_t n_lines, uint64_t inner,
+                                                    uint64_t outer_stride, uint64_t stride, uint32_t n) {
+    const uint64_t line = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (line >= n_lines) return;
+    uint8_t* p = dist + (line % inner) + (line / inner) * outer_stride;
+    uint32_t run = 255;
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(uint64_t)(i + k) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            run = run + 1u < v[k] ? run + 1u : v[k];
+            if (run != v[k]) p[(uint64_t)(i + k) * stride] = (uint8_t)run;
+        }
+    }
+    for (; i < n; ++i) {
+        const uint32_t v = p[(uint64_t)i * stride];
+        run = run + 1u < v ? run + 1u : v;
+        if (run != v) p[(uint64_t)i * stride] = (uint8_t)run;
+    }
+    run = 255;
+    i = n;
+    for (; i >= 8; i -= 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(uint64_t)(i - 1 - k) * stride];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            run = run + 1u < v[k] ? run + 1u : v[k];
+            if (run != v[k]) p[(uint64_t)(i - 1 - k) * stride] = (uint8_t)run;
+        }
+    }
+    for (; i > 0; --i) {
+        const uint32_t v = p[(uint64_t)(i - 1) * stride];
+        run = run + 1u < v ? run + 1u : v;
+        if (run != v) p[(uint64_t)(i - 1) * stride] = (uint8_t)run;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // mesh bounds (computeMeshBounds, SceneCreator.cpp:49-84)
 // ------------------------------------------------------------------------------------------
 // The reference folds sequentially with `if (c < mn) mn = c` from +FLT_MAX (and the mirror image for
@@ -652,6 +746,25 @@ hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint
     const uint64_t lanes = (face_words * 32 + 255) / 256 * 256;
     if (lanes == 0) return hipSuccess;
     k_face_bits<<<(unsigned)(lanes / 256), 256, 0, s>>>(indices, n_refs, offsets, g, n_tris, ranges, vox_of, face_bits, face_words);
+    return hipGetLastError();
+}
+
+hipError_t launch_distance_field(const uint32_t* offsets, const GridParams& g, uint8_t* dist, hipStream_t s) {
+    const uint64_t nx = (uint64_t)g.nx, ny = (uint64_t)g.ny, nz = (uint64_t)g.nz;
+    {
+        const uint64_t lines = ny * nz;
+        uint64_t blocks = (lines + 3) / 4;
+        if (blocks > 65536) blocks = 65536;
+        k_dist_x<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
+    }
+    if (ny > 1) {
+        const uint64_t lines = nx * nz;
+        k_dist_sweep<<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, nx, nx * ny, nx, (uint32_t)ny);
+    }
+    if (nz > 1) {
+        const uint64_t lines = nx * ny;
+        k_dist_sweep<<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, lines, 0, nx * ny, (uint32_t)nz);
+    }
     return hipGetLastError();
 }
 

@@ -40,6 +40,9 @@ struct SceneDev {
     // listed in the voxel's -x / +x / -y / +y / -z / +z neighbour (k_face_bits).  Always present.
     const uint32_t* face_bits;
     uint64_t face_words;
+    // dist: one byte per voxel, min(255, city-block distance to the nearest occupied voxel), 0 = occupied
+    // (k_dist_x / k_dist_sweep).  Lets the traversal step through empty space without looking at it.
+    const uint8_t* dist;
 };
 
 struct RenderArgs {
@@ -89,6 +92,7 @@ hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint
                             uint32_t n_tris, const uint32_t* ranges /* null: search the neighbour lists */,
                             const uint32_t* vox_of /* null: search the offsets */,
                             uint32_t* face_bits, uint64_t face_words, hipStream_t s);
+hipError_t launch_distance_field(const uint32_t* offsets, const GridParams& g, uint8_t* dist, hipStream_t s);
 hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s);
 hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* blocks x 6 + idx */,
                          uint64_t* partial_idx, int n_blocks, float* out6, hipStream_t s);

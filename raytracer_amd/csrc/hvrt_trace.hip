@@ -114,7 +114,9 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
     uint32_t face = NO_FACE;
     uint32_t b0, b1;
     bool alive = true;
+#ifndef HVRT_DIAG
     if (COUNT) r.nv = 1;
+#endif
 
     // cxy picks the x-or-y candidate, c2 compares that candidate with z: the nested ifs of :204-259
 #define HVRT_ADVANCE()                                                          \
@@ -136,17 +138,45 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
         b0 = pv[0]; b1 = pv[1];                                                 \
     } while (0)
 
-    HVRT_LOAD_VOXEL();
+    const uint8_t* __restrict__ dist = sc.dist;
     for (;;) {
-        // phase 1: walk through empty voxels (testVoxelTriangles on an unoccupied voxel does nothing)
-        while (alive && b0 == b1) {
-            HVRT_ADVANCE();
-            if (alive) {
-                HVRT_LOAD_VOXEL();
-                if (COUNT) ++r.nv;
+        // phase 1: walk to the next occupied voxel (testVoxelTriangles on an unoccupied voxel does nothing).
+        // dist[f] = city-block distance to the nearest occupied voxel (0 = occupied): a ray moves one face
+        // per step, so the next dist-1 voxels are empty whatever the ray does and are stepped through without
+        // being looked at.  The look-ups stay wave-synchronous -- all searching lanes read, then all take
+        // k <= min(dist) steps (k a power of two, found with ballots: one compare near a surface, where
+        // k = 1, a few in open space) -- because a vector load costs the L1 a slot per quad of lanes, however
+        // few of them want it.
+        bool search = alive;
+        for (;;) {
+            uint32_t dd = 255u;
+            if (search) dd = dist[f];
+            search = search && dd != 0u;
+            if (__ballot(search) == 0ull) break;
+            const uint32_t ds = search ? dd : 255u;
+            int k = 1;
+            if (__ballot(ds < 2u) == 0ull) {
+                k = 2;
+                if (__ballot(ds < 4u) == 0ull) {
+                    k = 4;
+                    if (__ballot(ds < 8u) == 0ull) {
+                        k = 8;
+                        if (__ballot(ds < 16u) == 0ull) k = __ballot(ds < 32u) == 0ull ? 32 : 16;
+                    }
+                }
+            }
+            for (int i = 0; i < k; ++i) {
+                if (search) {
+                    HVRT_ADVANCE();
+                    search = alive;
+#ifndef HVRT_DIAG
+                    if (COUNT && alive) ++r.nv;
+#endif
+                }
             }
         }
         if (!alive) break;
+        HVRT_LOAD_VOXEL();
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         bool found = false;
         {
@@ -170,6 +200,9 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                     todo &= todo - 1;
                     const uint32_t j = base + k;
                     float t;
+#ifdef HVRT_DIAG   // diagnostic build only: nt = tests executed, nv = 64 x wave-level test iterations
+                    if (COUNT) { ++r.nt; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) r.nv += 64; }
+#endif
                     if (INLINE) {
                         const float4* __restrict__ rec = sc.ref_rec + 3ull * j;
                         // 36 of the record's 48 bytes; the triangle id (10th dword) is fetched only on a hit
@@ -189,12 +222,15 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                 }
             }
         }
+#ifndef HVRT_DIAG
         if (COUNT) r.nt += b1 - b0;
+#endif
         if (found) break;   // :326-329
         HVRT_ADVANCE();
         if (!alive) break;
-        HVRT_LOAD_VOXEL();
+#ifndef HVRT_DIAG
         if (COUNT) ++r.nv;
+#endif
     }
 #undef HVRT_ADVANCE
 #undef HVRT_LOAD_VOXEL

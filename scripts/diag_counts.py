@@ -1,0 +1,21 @@
+"""Diagnostic build only (libhvrt_diag.so, -DHVRT_DIAG): tests actually executed per ray and wave-level test iterations."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["HVRT_LIB"] = os.path.join(ROOT, "raytracer_amd", "lib", "libhvrt_diag.so")
+import numpy as np
+import raytracer_amd as ra
+from raytracer_amd import capi, meshgen
+
+tris, g, W, H = meshgen.cube_sphere(289), 256, 3840, 2160
+ctx = ra.Context(0)
+ctx.set_mesh(tris)
+mn, mx = ctx.mesh_bounds()
+vs = capi.voxel_size(mn, mx, g, g, g)
+ctx.build_grid(g, g, g, mn, mx, vs)
+pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
+cam = capi.make_camera_frame(pos, la, up, fov, asp)
+cnt = ctx.render(cam, W, H)[3]
+n = W * H
+print(f"tests executed per ray {cnt[1]/n:.2f}; wave test iterations per ray-slot {cnt[0]/n:.2f} (x64 lanes)")
+ctx.close()
