@@ -47,12 +47,13 @@ __device__ __forceinline__ V3 normalize(V3 v) {
 __device__ __forceinline__ bool ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t_out) {
     V3 p = cross(d, e2);
     float det = dot(e1, p);
-    if (det > -EPS && det < EPS) return false;
     V3 s = sub(o, v0);
     float su = dot(s, p);
     const float r = __builtin_amdgcn_rcpf(det);
     const float ua = su * r;
-    if (ua < -1e-3f || ua > 1.001f) return false;
+    // one exit for "parallel" (the reference's first test) and "u far outside": no branch sits between the
+    // record's loads, so they are issued together instead of v0 waiting for the determinant
+    if ((det > -EPS && det < EPS) | (ua < -1e-3f) | (ua > 1.001f)) return false;
     V3 q = cross(s, e1);
     float sv = dot(d, q);
     const float va = sv * r;
