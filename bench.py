@@ -179,7 +179,8 @@ def main():
                        "outputs": "rgb+hit_id+t" if world == 1 else "rgb, all_gather + reassemble"},
             "voxel_build_ms": build_ms,
             "voxel_build_breakdown_ms": {"count": tmb.build_count_ms, "scan": tmb.build_scan_ms,
-                                         "fill": tmb.build_fill_ms, "sort": tmb.build_sort_ms},
+                                         "fill": tmb.build_fill_ms, "sort": tmb.build_sort_ms,
+                                         "distance_field+face_bits+records": tmb.build_expand_ms},
             "scene": {"refs": int(info.n_refs), "occupied_voxels": int(info.n_occupied), "max_list": int(info.max_list),
                       "voxels_per_ray": V, "tri_tests_per_ray": T, "hit_fraction": hit_frac},
         }

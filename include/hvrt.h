@@ -150,6 +150,11 @@ int hvrt_get_grid_info(const hvrt_ctx* ctx, hvrt_grid_info* out);
 /* Replaces: reading VoxelGrid::voxels[x][y][z].{triangle_start_idx,triangle_count} and
  * VoxelGrid::triangle_indices.  Copies the CSR to host memory; either pointer may be NULL. */
 int hvrt_get_csr(hvrt_ctx* ctx, uint32_t* offsets, uint32_t* indices);
+/* Copies the empty-space distance field to host memory: one byte per voxel in the CSR's voxel order,
+ * min(255, city-block distance in voxels to the nearest occupied voxel), 0 for an occupied voxel.  No
+ * reference counterpart: the reference steps through every empty voxel (OctreeLikeRayTracer.cpp:316-334);
+ * this array only lets the traversal skip looking at voxels that cannot be occupied.  For tests and tools. */
+int hvrt_get_distance_field(hvrt_ctx* ctx, uint8_t* dist);
 /* Device addresses of the resident arrays (for RCCL broadcast by the caller). */
 int hvrt_get_device_arrays(hvrt_ctx* ctx, void** d_tri_aos, void** d_offsets, void** d_indices);
 

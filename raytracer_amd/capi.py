@@ -23,7 +23,7 @@ SYMBOLS = [
     "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_set_stream", "hvrt_synchronize", "hvrt_get_timings",
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
-    "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device",
+    "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace",
 ]
 
@@ -98,6 +98,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_set_grid_csr_device.argtypes = [vp, C.c_int, C.c_int, C.c_int, f3, f3, f3, vp, vp, C.c_uint64]
     lib.hvrt_get_grid_info.argtypes = [vp, C.POINTER(GridInfo)]
     lib.hvrt_get_csr.argtypes = [vp, vp, vp]
+    lib.hvrt_get_distance_field.argtypes = [vp, vp]
     lib.hvrt_get_device_arrays.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.hvrt_export_scene_device.argtypes = [vp, vp, vp, vp]
     lib.hvrt_make_camera_frame.argtypes = [f3, f3, f3, C.c_float, C.c_float, C.POINTER(CameraFrame)]
@@ -252,6 +253,13 @@ class Context:
         idx = np.empty(gi.n_refs, np.uint32)
         self._ck(self._lib.hvrt_get_csr(self._h, _ptr(off), _ptr(idx) if idx.size else None))
         return off, idx
+
+    def distance_field(self) -> np.ndarray:
+        """(nz, ny, nx) uint8: min(255, city-block distance to the nearest occupied voxel)."""
+        gi = self.grid_info()
+        out = np.empty(gi.n_voxels, np.uint8)
+        self._ck(self._lib.hvrt_get_distance_field(self._h, _ptr(out)))
+        return out.reshape(gi.nz, gi.ny, gi.nx)
 
     def device_arrays(self):
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()

@@ -478,6 +478,16 @@ int hvrt_get_csr(hvrt_ctx* c, uint32_t* offsets, uint32_t* indices) {
     return HVRT_OK;
 }
 
+int hvrt_get_distance_field(hvrt_ctx* c, uint8_t* dist) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "get_distance_field: no grid");
+    if (!dist) return fail(c, HVRT_ERR_INVALID, "get_distance_field: null output");
+    HIP_TRY(c, hipMemcpyAsync(dist, c->dist, c->g.nvox, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HVRT_OK;
+}
+
 int hvrt_get_device_arrays(hvrt_ctx* c, void** d_tri_aos, void** d_offsets, void** d_indices) {
     if (!c) return HVRT_ERR_INVALID;
     if (d_tri_aos) *d_tri_aos = c->tri_aos;

@@ -557,46 +557,149 @@ __global__ __launch_bounds__(256) void k_dist_x(const uint32_t* __restrict__ off
     }
 }
 
+// x pass, fast form (nx a multiple of 4, at most 16384): a lane takes four neighbouring voxels, a wave 256 per
+// step, and the line is read twice (the second time from cache) instead of being written twice: the first
+// loop leaves the first / last occupied voxel of chunk c in lane c, two wave scans turn those into "last
+// occupied before" / "first occupied after" each chunk, and the second loop writes the finished bytes, one
+// dword per lane.
+__global__ __launch_bounds__(256) void k_dist_x4(const uint32_t* __restrict__ offsets, uint8_t* __restrict__ dist,
+                                                 uint32_t nx, uint64_t n_lines) {
+    constexpr int FAR = 1 << 30;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * 256u) >> 6;
+    const uint32_t n_chunks = (nx + 255u) / 256u;
+    for (uint64_t line = wave0; line < n_lines; line += n_waves) {
+        const uint32_t* o = offsets + line * nx;
+        uint8_t* p = dist + line * nx;
+        auto nibble = [&](uint32_t c) -> uint32_t {
+            const uint32_t i0 = c * 256u + 4u * (uint32_t)lane;
+            uint32_t nib = 0;
+            if (i0 < nx) {
+                uint32_t v[5];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) v[k] = o[i0 + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nib |= (v[k + 1] != v[k] ? 1u : 0u) << k;
+            }
+            return nib;
+        };
+        int my_first = FAR, my_last = -FAR;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint32_t nib = nibble(c);
+            const unsigned long long H = __ballot(nib != 0);
+            const int lo = nib ? __builtin_ctz(nib) : 0, hi = nib ? 31 - __builtin_clz(nib) : 0;
+            if (H) {
+                const int fl = __builtin_ctzll(H), ll = 63 - __builtin_clzll(H);
+                const int first = (int)(c * 256u) + 4 * fl + __shfl(lo, fl);
+                const int last = (int)(c * 256u) + 4 * ll + __shfl(hi, ll);
+                if (lane == (int)c) { my_first = first; my_last = last; }
+            }
+        }
+        int inc_last = my_last, inc_first = my_first;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int a = __shfl_up(inc_last, d), b = __shfl_down(inc_first, d);
+            if (lane >= d) inc_last = a > inc_last ? a : inc_last;
+            if (lane + d < 64) inc_first = b < inc_first ? b : inc_first;
+        }
+        int before = __shfl_up(inc_last, 1), after = __shfl_down(inc_first, 1);
+        if (lane == 0) before = -FAR;
+        if (lane == 63) after = FAR;
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint32_t nib = nibble(c);
+            const unsigned long long H = __ballot(nib != 0);
+            const int lo = nib ? __builtin_ctz(nib) : 0, hi = nib ? 31 - __builtin_clz(nib) : 0;
+            const int left = __shfl(before, (int)c), right = __shfl(after, (int)c);
+            const unsigned long long Hb = H & ((1ull << lane) - 1ull);        // lanes below me with an occupied voxel
+            const unsigned long long Ha = H & ~((2ull << lane) - 1ull);       // lanes above me
+            const int lb = Hb ? 63 - __builtin_clzll(Hb) : lane, la = Ha ? __builtin_ctzll(Ha) : lane;
+            const int hi_b = __shfl(hi, lb), lo_a = __shfl(lo, la);
+            const int cbase = (int)(c * 256u);
+            const int prev_other = Hb ? cbase + 4 * lb + hi_b : left;
+            const int next_other = Ha ? cbase + 4 * la + lo_a : right;
+            const int base = cbase + 4 * lane;
+            uint32_t word = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t mlo = nib & ((2u << k) - 1u), mhi = nib >> k;
+                const int prev = mlo ? base + 31 - __builtin_clz(mlo) : prev_other;
+                const int next = mhi ? base + k + __builtin_ctz(mhi) : next_other;
+                const int i = base + k;
+                int dmin = i - prev < next - i ? i - prev : next - i;
+                dmin = dmin > 255 ? 255 : dmin;
+                word |= (uint32_t)dmin << (8 * k);
+            }
+            if ((uint32_t)base < nx) *reinterpret_cast<uint32_t*>(p + base) = word;
+        }
+    }
+}
+
 // y and z passes: one lane per line (lines are indexed so that neighbouring lanes are neighbouring x: every
-// access of a wave is one 64-byte run); eight loads in flight per lane.
+// access of a wave is one contiguous run); sixteen loads in flight per lane.  With W = 4 a lane carries four
+// neighbouring lines in one dword (needs the line starts and the stride to be multiples of 4).
+template <int W> struct DistWord;
+template <> struct DistWord<1> { using T = uint8_t; };
+template <> struct DistWord<4> { using T = uint32_t; };
+
+template <int W>
+__device__ __forceinline__ uint32_t dist_relax(uint32_t (&run)[W], uint32_t v) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < W; ++b) {
+        const uint32_t vb = (v >> (8 * b)) & 0xFFu;
+        run[b] = run[b] + 1u < vb ? run[b] + 1u : vb;
+        out |= run[b] << (8 * b);
+    }
+    return out;
+}
+
+template <int W>
 __global__ __launch_bounds__(256) void k_dist_sweep(uint8_t* __restrict__ dist, uint64_t n_lines, uint64_t inner,
                                                     uint64_t outer_stride, uint64_t stride, uint32_t n) {
-    const uint64_t line = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    using T = typename DistWord<W>::T;
+    constexpr uint32_t U = 16;   // loads in flight per lane: small grids have few lines, and each is a serial chain
+    const uint64_t line = (uint64_t)blockIdx.x * 256u + threadIdx.x;   // in units of W lines
     if (line >= n_lines) return;
-    uint8_t* p = dist + (line % inner) + (line / inner) * outer_stride;
-    uint32_t run = 255;
+    const uint64_t first = line * W;
+    uint8_t* p = dist + (first % inner) + (first / inner) * outer_stride;
+    auto at = [&](uint32_t i) -> T& { return *reinterpret_cast<T*>(p + (uint64_t)i * stride); };
+    uint32_t run[W];
+#pragma unroll
+    for (int b = 0; b < W; ++b) run[b] = 255;
     uint32_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint32_t v[8];
+    for (; i + U <= n; i += U) {
+        uint32_t v[U];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = p[(uint64_t)(i + k) * stride];
+        for (int k = 0; k < U; ++k) v[k] = at(i + k);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            run = run + 1u < v[k] ? run + 1u : v[k];
-            if (run != v[k]) p[(uint64_t)(i + k) * stride] = (uint8_t)run;
+        for (int k = 0; k < U; ++k) {
+            const uint32_t o = dist_relax<W>(run, v[k]);
+            if (o != v[k]) at(i + k) = (T)o;
         }
     }
     for (; i < n; ++i) {
-        const uint32_t v = p[(uint64_t)i * stride];
-        run = run + 1u < v ? run + 1u : v;
-        if (run != v) p[(uint64_t)i * stride] = (uint8_t)run;
+        const uint32_t v = at(i);
+        const uint32_t o = dist_relax<W>(run, v);
+        if (o != v) at(i) = (T)o;
     }
-    run = 255;
+#pragma unroll
+    for (int b = 0; b < W; ++b) run[b] = 255;
     i = n;
-    for (; i >= 8; i -= 8) {
-        uint32_t v[8];
+    for (; i >= U; i -= U) {
+        uint32_t v[U];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = p[(uint64_t)(i - 1 - k) * stride];
+        for (int k = 0; k < U; ++k) v[k] = at(i - 1 - k);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            run = run + 1u < v[k] ? run + 1u : v[k];
-            if (run != v[k]) p[(uint64_t)(i - 1 - k) * stride] = (uint8_t)run;
+        for (int k = 0; k < U; ++k) {
+            const uint32_t o = dist_relax<W>(run, v[k]);
+            if (o != v[k]) at(i - 1 - k) = (T)o;
         }
     }
     for (; i > 0; --i) {
-        const uint32_t v = p[(uint64_t)(i - 1) * stride];
-        run = run + 1u < v ? run + 1u : v;
-        if (run != v) p[(uint64_t)(i - 1) * stride] = (uint8_t)run;
+        const uint32_t v = at(i - 1);
+        const uint32_t o = dist_relax<W>(run, v);
+        if (o != v) at(i - 1) = (T)o;
     }
 }
 
@@ -755,15 +858,19 @@ hipError_t launch_distance_field(const uint32_t* offsets, const GridParams& g, u
         const uint64_t lines = ny * nz;
         uint64_t blocks = (lines + 3) / 4;
         if (blocks > 65536) blocks = 65536;
-        k_dist_x<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
+        if (nx % 4 == 0 && nx <= 16384) k_dist_x4<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
+        else k_dist_x<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
     }
+    // four lines per lane where line starts and strides are multiples of 4 (dist itself is 256-B aligned)
     if (ny > 1) {
         const uint64_t lines = nx * nz;
-        k_dist_sweep<<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, nx, nx * ny, nx, (uint32_t)ny);
+        if (nx % 4 == 0) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, nx, nx * ny, nx, (uint32_t)ny);
+        else k_dist_sweep<1><<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, nx, nx * ny, nx, (uint32_t)ny);
     }
     if (nz > 1) {
         const uint64_t lines = nx * ny;
-        k_dist_sweep<<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, lines, 0, nx * ny, (uint32_t)nz);
+        if (lines % 4 == 0) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, lines, 0, lines, (uint32_t)nz);
+        else k_dist_sweep<1><<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, lines, 0, lines, (uint32_t)nz);
     }
     return hipGetLastError();
 }

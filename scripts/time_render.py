@@ -13,8 +13,11 @@ if which == "c2":
     tris, g, W, H = meshgen.cube_sphere(289), 256, 3840, 2160
 elif which == "c3":
     tris, g, W, H = meshgen.skewed_statue(289, 2100), 512, 3840, 2160     # 1.0M base + 8.8M patch
+elif which == "c4":
+    tris, g, W, H = meshgen.cube_sphere(289), 256, 7680, 4320                 # config 2 scene at 8K, 16 spp
 elif which == "small":
     tris, g, W, H = meshgen.cube_sphere(58), 50, 800, 600
+spp = 16 if which == "c4" else 1
 ctx = ra.Context(0)
 ctx.set_mesh(tris)
 mn, mx = ctx.mesh_bounds()
@@ -33,8 +36,8 @@ t = torch.empty((H, W), dtype=torch.float32, device="cuda:0")
 torch.cuda.synchronize()
 ms = []
 for i in range(reps + 2):
-    ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
+    ctx.render_part_device(cam, W, H, spp, 1, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
     ctx.synchronize()
     if i >= 2: ms.append(ctx.timings().render_ms)
-print(f"render {W}x{H}: mean {np.mean(ms):.3f} ms min {np.min(ms):.3f} ms -> {W*H/np.mean(ms)/1e3:.1f} Mrays/s; checksum hit {int(hit.long().sum())}", flush=True)
+print(f"render {W}x{H} spp {spp}: mean {np.mean(ms):.3f} ms min {np.min(ms):.3f} ms -> {W*H*spp/np.mean(ms)/1e3:.1f} Mrays/s; checksum hit {int(hit.long().sum())}", flush=True)
 ctx.close()

@@ -8,6 +8,26 @@ from raytracer_amd import capi, meshgen
 pytestmark = pytest.mark.gpu
 
 
+def l1_distance(occ):
+    """min(255, city-block distance to the nearest True cell) of a (nz, ny, nx) mask -- plain numpy sweeps."""
+    d = np.where(occ, 0, 1 << 20).astype(np.int64)
+    for ax in range(3):
+        v = np.moveaxis(d, ax, 0)
+        for i in range(1, v.shape[0]):
+            np.minimum(v[i], v[i - 1] + 1, out=v[i])
+        for i in range(v.shape[0] - 2, -1, -1):
+            np.minimum(v[i], v[i + 1] + 1, out=v[i])
+    return np.minimum(d, 255).astype(np.uint8)
+
+
+def check_distance_field(ctx, off, dims):
+    nx, ny, nz = dims
+    occ = (np.diff(off.astype(np.int64)) > 0).reshape(nz, ny, nx)
+    got = ctx.distance_field()
+    want = l1_distance(occ)
+    assert np.array_equal(got, want), f"distance field differs in {int((got != want).sum())} voxels"
+
+
 def build_both(ctx, tris, dims, points=None):
     nx, ny, nz = dims
     ctx.set_mesh(tris)
@@ -25,6 +45,7 @@ def build_both(ctx, tris, dims, points=None):
     cnt = np.diff(ooff.astype(np.int64))
     assert info.n_refs == oidx.size and info.n_occupied == int((cnt > 0).sum())
     assert info.max_list == (int(cnt.max()) if cnt.size else 0)
+    check_distance_field(ctx, off, dims)
     return info, off, idx, mn, mx, vs
 
 
@@ -135,6 +156,22 @@ def test_ingest_cpu_built_csr_round_trip(ctx):
     info = ctx.grid_info()
     cnt = np.diff(sc.offsets.astype(np.int64))
     assert info.n_occupied == int((cnt > 0).sum()) and info.max_list == int(cnt.max())
+
+
+@pytest.mark.parametrize("dims,fill", [((520, 3, 2), 0.01), ((1028, 2, 1), 0.003), ((70, 5, 3), 0.02), ((256, 9, 7), 0.0),
+                                       ((64, 64, 64), 0.0005), ((300, 1, 1), 0.01), ((4, 300, 2), 0.02), ((16388, 1, 2), 0.0002)])
+def test_distance_field_of_ingested_grids(ctx, dims, fill):
+    """Every kernel variant of the empty-space distance field (4-voxel and 1-voxel x pass, packed and plain
+    sweeps, saturation at 255, an empty grid) against plain numpy sweeps, on synthetic occupancy."""
+    nx, ny, nz = dims
+    rng = np.random.default_rng(nx * 31 + ny * 7 + nz)
+    occ = rng.random(nx * ny * nz) < fill
+    off = np.concatenate([[0], np.cumsum(occ)]).astype(np.uint32)
+    idx = np.zeros(int(occ.sum()), np.uint32)
+    ctx.set_mesh(meshgen.box())
+    one = np.ones(3, np.float32)
+    ctx.set_grid_csr(nx, ny, nz, np.zeros(3, np.float32), one * max(dims), one, off, idx)
+    check_distance_field(ctx, off, dims)
 
 
 def test_errors_are_reported_not_swallowed(ctx):
