@@ -1,0 +1,140 @@
+"""GPU rehearsal of the multi-GPU path on ONE card (the N > 1 run itself belongs to the driver).
+
+RCCL refuses two ranks on one device, so the exchange is rehearsed in three pieces, each through the
+product code that runs at N > 1:
+  * scene replication: export on one context, ingest through the *_device entry points on another, render;
+  * DistributedRenderer.render_frames with world = 2 and 3, with torch.distributed's all_gather replaced by
+    a stand-in that supplies the other ranks' slabs (rendered beforehand through the C ABI) -- the stream
+    choreography, the slab layout and the reassembly are the real ones;
+  * a real one-rank "nccl" (RCCL) process group on the card: broadcast / all_gather_into_tensor / barrier
+    with the argument forms distributed.py and bench.py use.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import raytracer_amd as ra
+from raytracer_amd import capi, meshgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(ctx, n=16, g=24):
+    tris = meshgen.cube_sphere(n)
+    ctx.set_mesh(tris)
+    mn, mx = ctx.mesh_bounds()
+    vs = capi.voxel_size(mn, mx, g, g, g)
+    ctx.build_grid(g, g, g, mn, mx, vs)
+    pos, la, up, fov, asp = capi.default_camera(mn, mx)
+    return tris, mn, mx, vs, capi.make_camera_frame(pos, la, up, fov, asp)
+
+
+def test_scene_replication_through_device_entry_points(ctx):
+    import torch
+    g = 24
+    tris, mn, mx, vs, cam = _scene(ctx, 16, g)
+    info = ctx.grid_info()
+    dev = torch.device("cuda:0")
+    tri = torch.empty(info.n_triangles * 12, dtype=torch.float32, device=dev)
+    off = torch.empty(g ** 3 + 1, dtype=torch.int32, device=dev)
+    idx = torch.empty(info.n_refs, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.export_scene_device(tri.data_ptr(), off.data_ptr(), idx.data_ptr())
+    ctx.synchronize()
+    want = ctx.render(cam, 160, 120)
+    other = ra.Context(0)
+    try:
+        other.set_mesh_device(tri.data_ptr(), info.n_triangles)
+        vs3 = np.full(3, vs, np.float32)
+        other.set_grid_csr_device(g, g, g, mn, mx, vs3, off.data_ptr(), idx.data_ptr(), info.n_refs)
+        got = other.render(cam, 160, 120)
+        a, b = ctx.get_csr(), other.get_csr()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert np.array_equal(ctx.distance_field(), other.distance_field())
+    finally:
+        other.close()
+    for w, gt in zip(want, got):
+        assert np.array_equal(w.view(np.uint32) if w.dtype == np.float32 else w,
+                              gt.view(np.uint32) if gt.dtype == np.float32 else gt)
+
+
+@pytest.mark.parametrize("world,tile_rows,H", [(2, 16, 150), (3, 8, 97), (8, 16, 130)])
+def test_render_frames_with_stand_in_all_gather(ctx, monkeypatch, world, tile_rows, H):
+    import torch
+    from raytracer_amd import distributed as D
+    tris, mn, mx, vs, cam = _scene(ctx, 16, 24)
+    W = 200
+    dev = torch.device("cuda:0")
+    full = ctx.render(cam, W, H)[0]
+    cam2 = capi.make_camera_frame(*capi.default_camera(mn, mx, "side"))
+    full2 = ctx.render(cam2, W, H)[0]
+    part = D.Partition(H, tile_rows, world)
+    # the other ranks' slabs, rendered beforehand
+    slabs = {}
+    for f, c in enumerate((cam, cam2)):
+        for p in range(world):
+            s = torch.zeros((part.slab_rows, W, 3), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            ctx.render_part_device(c, W, H, 1, 0, tile_rows, p, world, d_rgb=s.data_ptr())
+            ctx.synchronize()
+            slabs[(f, p)] = s
+    for rank in range(world):
+        calls = []
+
+        def fake_all_gather(out, inp, group=None, async_op=False, _rank=rank, _calls=calls):
+            f = len(_calls)
+            _calls.append(f)
+            for p in range(world):
+                out[p].copy_(inp if p == _rank else slabs[(f, p)])
+
+        monkeypatch.setattr(D.dist, "all_gather_into_tensor", fake_all_gather)
+        dr = D.DistributedRenderer(ctx, rank, world, dev, tile_rows=tile_rows)
+        dr.alloc(W, H, n_frames=2)
+        frames = dr.render_frames([cam, cam2])
+        torch.cuda.synchronize()
+        got = frames.cpu().numpy()
+        assert len(calls) == 2
+        assert np.array_equal(got[0].view(np.uint32), full.view(np.uint32)), f"frame 0 differs on rank {rank}"
+        assert np.array_equal(got[1].view(np.uint32), full2.view(np.uint32)), f"frame 1 differs on rank {rank}"
+
+
+def test_one_rank_rccl_group_collectives_and_renderer(ctx):
+    """backend "nccl" is RCCL here: the calls distributed.py / bench.py make, on a real one-rank group."""
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import distributed as D
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        x = torch.arange(1024, dtype=torch.float32, device=dev)
+        dist.broadcast(x, src=0)
+        out = torch.empty((1, 1024), dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(out, x)
+        tt = torch.tensor([1.5], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], x) and float(tt.item()) == 1.5
+        assert torch.equal(D.gather_parts(x)[0], x)
+        dr = D.DistributedRenderer(ctx, 0, 1, dev, tile_rows=16)
+        tris = meshgen.cube_sphere(16)
+        mn, mx, vs3 = dr.replicate_scene(tris, (24, 24, 24))
+        cam = capi.make_camera_frame(*capi.default_camera(mn, mx))
+        dr.alloc(200, 150, n_frames=2)
+        frames = dr.render_frames([cam, cam])
+        torch.cuda.synchronize()
+        want = ctx.render(cam, 200, 150)[0]
+        assert np.array_equal(frames[0].cpu().numpy().view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(frames[1].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    finally:
+        dist.destroy_process_group()
