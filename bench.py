@@ -137,15 +137,20 @@ def main():
             ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
         rays_per_step = W * H
     else:
-        dr.alloc(W, H, n_frames=world)
+        # weak scaling: a batch of `world` frames per step; every rank traces its row tiles of every frame
+        # (one frame's worth of rays per rank), one all_to_all hands frame f to rank f, which reassembles it.
+        # The exchange of batch k overlaps the traversal of batch k+1.
+        dr.alloc_batch(W, H)
         cams = [cam] * world
 
         def step():
-            dr.render_frames(cams)
+            dr.render_batch(cams)
         rays_per_step = W * H * world
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        dr.flush()
     barrier()
     t0 = time.perf_counter()
     if world == 1:
@@ -159,6 +164,7 @@ def main():
     else:
         for _ in range(args.steps):
             step()
+        dr.flush()             # the last batch's exchange + reassembly belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -176,7 +182,7 @@ def main():
             "config": {"workload": args.workload, "mesh": f"cube-sphere n={n_sphere}", "triangles": int(info.n_triangles),
                        "grid": [g, g, g], "image": [W, H], "spp": 1, "camera": "reference front rule, aspect=W/H",
                        "frames_per_step": world, "tile_rows": 16,
-                       "outputs": "rgb+hit_id+t" if world == 1 else "rgb, all_gather + reassemble"},
+                       "outputs": "rgb+hit_id+t" if world == 1 else "rgb; all_to_all of row-tile slabs, frame f reassembled on rank f"},
             "voxel_build_ms": build_ms,
             "voxel_build_breakdown_ms": {"count": tmb.build_count_ms, "scan": tmb.build_scan_ms,
                                          "fill": tmb.build_fill_ms, "sort": tmb.build_sort_ms,

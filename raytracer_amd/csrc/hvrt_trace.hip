@@ -110,9 +110,10 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
 
     const uint32_t* __restrict__ offs = sc.offsets;
     // face through which the current voxel was entered: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z neighbour
+    // (kept as the last step's index increment; decoded only when a voxel has a list to test)
     constexpr uint32_t NO_FACE = 6;
     const uint32_t facex = px ? 0u : 1u, facey = py ? 2u : 3u, facez = pz ? 4u : 5u;
-    uint32_t face = NO_FACE;
+    uint32_t last = 0;   // 0 = no step taken yet (an increment is never 0)
     uint32_t b0, b1;
     bool alive = true;
 #ifndef HVRT_DIAG
@@ -129,8 +130,8 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
         tmy = sty ? tmy + tdy : tmy;                                            \
         tmz = c2 ? tmz : tmz + tdz;                                             \
         rx -= stx ? 1 : 0; ry -= sty ? 1 : 0; rz -= c2 ? 0 : 1;                 \
-        f += c2 ? (cxy ? fsx : fsy) : fsz;                                      \
-        face = c2 ? (cxy ? facex : facey) : facez;                              \
+        last = c2 ? (cxy ? fsx : fsy) : fsz;                                    \
+        f += last;                                                              \
         alive = (rx | ry | rz) >= 0;                                            \
     } while (0)
 #define HVRT_LOAD_VOXEL()                                                       \
@@ -178,6 +179,11 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
         }
         if (!alive) break;
         HVRT_LOAD_VOXEL();
+        // a surviving x step implies nx > 1 (it would have left a 1-wide grid), so fsx, fsy, fsz are told
+        // apart by testing the axes in this order with their extent
+        const uint32_t face = last == 0u ? NO_FACE
+                            : (last == fsx && g.nx > 1) ? facex
+                            : (last == fsy && g.ny > 1) ? facey : facez;
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         bool found = false;
         {

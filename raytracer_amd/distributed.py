@@ -61,6 +61,22 @@ def gather_parts(local_slab: torch.Tensor, group=None) -> torch.Tensor:
     return out
 
 
+def exchange_parts(local: torch.Tensor, out: torch.Tensor | None = None, group=None, async_op: bool = False):
+    """Batch of `world` frames: local[f] is this rank's slab of frame f.  One all_to_all sends it to rank f and
+    brings in every rank's slab of frame `rank`: out[p] = part p of the frame this rank owns.  xGMI is a
+    point-to-point mesh, so this is its native pattern, and each rank moves (world-1)/world of ONE frame per
+    batch instead of world-1 frames as with an all_gather of every frame.  Returns (out, work or None)."""
+    world = dist.get_world_size(group)
+    assert local.shape[0] == world, "exchange_parts: one slab per rank expected"
+    if out is None:
+        out = torch.empty_like(local)
+    if world == 1:
+        out.copy_(local)
+        return out, None
+    work = dist.all_to_all_single(out, local.contiguous(), group=group, async_op=async_op)
+    return out, work
+
+
 def broadcast_arrays(tensors, src: int = 0, group=None):
     for t in tensors:
         dist.broadcast(t, src=src, group=group)
@@ -138,3 +154,59 @@ class DistributedRenderer:
                                            self.world, self.part.slab_rows, 12, self.frames[f].data_ptr())
         cur.wait_stream(self.stream)
         return self.frames
+
+    # ---- batches of `world` frames, one owner per frame (weak scaling) ---------------------------
+    def alloc_batch(self, width: int, height: int):
+        """Double-buffered: batch k renders while batch k-1 is exchanged."""
+        part = Partition(height, self.tile_rows, self.world)
+        self.part = part
+        shape = (self.world, part.slab_rows, width, 3)
+        self.b_local = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.b_recv = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.b_frame = [torch.empty((height, width, 3), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.width, self.height = width, height
+        self._batch = 0
+        self._pending = None       # (buffer index, work) of the batch whose exchange is in flight
+
+    def _finish_pending(self):
+        """Queues, on libhvrt's stream, the wait for the pending exchange and the reassembly of its frame."""
+        if self._pending is None:
+            return None
+        b, work = self._pending
+        self._pending = None
+        if self.world == 1:
+            return self.b_local[b][0, :self.height]
+        with torch.cuda.stream(self.stream):
+            if work is not None:
+                work.wait()                                # stream-level wait, the host does not block
+            self.ctx.assemble_parts_device(self.b_recv[b].data_ptr(), self.width, self.height, self.tile_rows,
+                                           self.world, self.part.slab_rows, 12, self.b_frame[b].data_ptr())
+        return self.b_frame[b]
+
+    def render_batch(self, cam_frames, spp: int = 1, seed: int = 0):
+        """Submits a batch of `world` frames: this rank renders its row tiles of every frame, then ONE
+        all_to_all hands frame f's slabs to rank f.  The exchange runs on RCCL's stream while the next
+        batch renders.  Returns the previous batch's frame owned by this rank (frame index == rank; valid
+        on torch's current stream), or None on the first call; flush() returns the last one."""
+        assert len(cam_frames) == self.world, "render_batch: one camera per rank"
+        b = self._batch & 1
+        self._batch += 1
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        for f, cam in enumerate(cam_frames):
+            self.ctx.render_part_device(cam, self.width, self.height, spp, seed, self.tile_rows, self.rank,
+                                        self.world, d_rgb=self.b_local[b][f].data_ptr())
+        work = None
+        if self.world > 1:
+            cur.wait_event(self.stream.record_event())     # RCCL's stream orders itself after `cur`
+            _, work = exchange_parts(self.b_local[b], self.b_recv[b], async_op=True)
+        done = self._finish_pending()                      # batch k-1: exchanged while batch k rendered
+        self._pending = (b, work)
+        cur.wait_stream(self.stream)
+        return done
+
+    def flush(self):
+        """Completes the batch in flight; returns its frame (valid on torch's current stream)."""
+        done = self._finish_pending()
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return done

@@ -73,6 +73,52 @@ def _worker(rank, world, port, tile_rows, W, H, out_dir):
         dist.destroy_process_group()
 
 
+def _worker_batch(rank, world, port, tile_rows, W, H, out_dir):
+    """Batch mode: `world` frames (different cameras), every rank renders its tiles of every frame, ONE
+    all_to_all (exchange_parts) hands frame f's slabs to rank f, which reassembles and checks it."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    from raytracer_amd import capi, meshgen
+    from raytracer_amd.distributed import Partition, exchange_parts
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc, mn, mx, vs = oracle.build_scene(meshgen.cube_sphere(10), 16, 16, 16)
+        views = ["front", "side", "top"]
+        frs = [oracle.camera_frame(*capi.default_camera(mn, mx, views[f % 3])) for f in range(world)]
+        part = Partition(H, tile_rows, world)
+        rows = part.global_rows(rank)
+        local = torch.zeros((world, part.slab_rows, W, 3), dtype=torch.float32)
+        for f in range(world):
+            for lr, y in enumerate(rows):
+                rgb, _, _, _ = sc.render(frs[f], W, H, threads=1, rows=(int(y), int(y) + 1))
+                local[f, lr] = torch.from_numpy(rgb[y])
+        recv, work = exchange_parts(local, async_op=True)
+        if work is not None:
+            work.wait()
+        frame = np.zeros((H, W, 3), np.float32)
+        for p in range(world):
+            pr = part.global_rows(p)
+            frame[pr] = recv[p, :len(pr)].numpy()
+        full, _, _, _ = sc.render(frs[rank], W, H, threads=1)     # the frame this rank owns
+        ok = torch.tensor([int(np.array_equal(frame.view(np.uint32), full.view(np.uint32)))])
+        dist.all_reduce(ok, dist.ReduceOp.MIN)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "ok_batch.npy"), ok.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,tile_rows,H", [(2, 16, 90), (3, 8, 50)])
+def test_batch_all_to_all_gives_every_rank_its_frame(tmp_path, world, tile_rows, H):
+    port = _free_port()
+    mp.spawn(_worker_batch, args=(world, port, tile_rows, 48, H, str(tmp_path)), nprocs=world, join=True)
+    assert np.load(tmp_path / "ok_batch.npy")[0] == 1
+
+
 @pytest.mark.parametrize("world,tile_rows,H", [(2, 16, 90), (2, 7, 45), (3, 8, 50)])
 def test_partition_gather_reassemble_equals_single_rank(tmp_path, world, tile_rows, H):
     port = _free_port()

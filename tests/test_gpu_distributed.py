@@ -100,6 +100,69 @@ def test_render_frames_with_stand_in_all_gather(ctx, monkeypatch, world, tile_ro
         assert np.array_equal(got[1].view(np.uint32), full2.view(np.uint32)), f"frame 1 differs on rank {rank}"
 
 
+class _StreamWork:
+    """What an asynchronous RCCL work handle does on wait(): the CURRENT stream waits for the collective."""
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.event)
+        return True
+
+
+@pytest.mark.parametrize("world,tile_rows,H", [(2, 16, 150), (4, 8, 97), (8, 16, 2160 // 8)])
+def test_render_batch_with_stand_in_all_to_all(ctx, monkeypatch, world, tile_rows, H):
+    """render_batch's double-buffered pipeline over four batches (cameras change per batch), with the
+    all_to_all replaced by a stand-in that delivers the other ranks' slabs of the frame this rank owns."""
+    import torch
+    from raytracer_amd import distributed as D
+    tris, mn, mx, vs, cam = _scene(ctx, 16, 24)
+    W = 200
+    dev = torch.device("cuda:0")
+    views = ["front", "side", "top"]
+    cams = [capi.make_camera_frame(*capi.default_camera(mn, mx, v)) for v in views]
+    fulls = [ctx.render(c, W, H)[0] for c in cams]
+    part = D.Partition(H, tile_rows, world)
+    slabs = {}
+    for v in range(3):
+        for p in range(world):
+            s = torch.zeros((part.slab_rows, W, 3), dtype=torch.float32, device=dev)
+            torch.cuda.synchronize()
+            ctx.render_part_device(cams[v], W, H, 1, 0, tile_rows, p, world, d_rgb=s.data_ptr())
+            ctx.synchronize()
+            slabs[(v, p)] = s
+    for rank in (0, world - 1):
+        batches = [[(k + f) % 3 for f in range(world)] for k in range(4)]     # view index per frame of batch k
+        state = {"k": 0}
+
+        def fake_a2a(out, inp, group=None, async_op=False, _rank=rank, _state=state):
+            k = _state["k"]
+            _state["k"] += 1
+            v = batches[k][_rank]                      # the frame this rank owns in batch k
+            for p in range(world):
+                out[p].copy_(inp[_rank] if p == _rank else slabs[(v, p)])
+            return _StreamWork(torch.cuda.current_stream().record_event())
+
+        monkeypatch.setattr(D.dist, "all_to_all_single", fake_a2a)
+        monkeypatch.setattr(D.dist, "get_world_size", lambda group=None: world)
+        dr = D.DistributedRenderer(ctx, rank, world, dev, tile_rows=tile_rows)
+        dr.alloc_batch(W, H)
+        got = []
+        for k in range(4):
+            done = dr.render_batch([cams[v] for v in batches[k]])
+            if done is not None:
+                torch.cuda.synchronize()
+                got.append(done.cpu().numpy().copy())
+        done = dr.flush()
+        torch.cuda.synchronize()
+        got.append(done.cpu().numpy().copy())
+        assert len(got) == 4 and state["k"] == 4
+        for k in range(4):
+            want = fulls[batches[k][rank]]
+            assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), f"batch {k} differs on rank {rank}"
+
+
 def test_one_rank_rccl_group_collectives_and_renderer(ctx):
     """backend "nccl" is RCCL here: the calls distributed.py / bench.py make, on a real one-rank group."""
     import torch
@@ -136,5 +199,19 @@ def test_one_rank_rccl_group_collectives_and_renderer(ctx):
         want = ctx.render(cam, 200, 150)[0]
         assert np.array_equal(frames[0].cpu().numpy().view(np.uint32), want.view(np.uint32))
         assert np.array_equal(frames[1].cpu().numpy().view(np.uint32), want.view(np.uint32))
+        # batch mode on the same one-rank group, and the all_to_all call form itself
+        y = torch.empty_like(out)
+        h = dist.all_to_all_single(y, out, async_op=True)
+        h.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(y, out)
+        dr.alloc_batch(200, 150)
+        assert dr.render_batch([cam]) is None
+        first = dr.render_batch([cam])
+        torch.cuda.synchronize()
+        assert np.array_equal(first.cpu().numpy().view(np.uint32), want.view(np.uint32))
+        last = dr.flush()
+        torch.cuda.synchronize()
+        assert np.array_equal(last.cpu().numpy().view(np.uint32), want.view(np.uint32))
     finally:
         dist.destroy_process_group()
