@@ -194,6 +194,22 @@ int hvrt_render(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int width, int he
 int hvrt_render_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int width, int height,
                             int spp, uint32_t seed, int tile_rows, int part, int n_parts,
                             void* d_rgb, void* d_hit_id, void* d_t, void* d_counters);
+
+/* Batch form of hvrt_render_part_device: n_frames camera frames (1..HVRT_MAX_BATCH_FRAMES, host array), ONE
+ * kernel launch whose work queue spans the tiles of every frame.  Frame f's rows of this part go to
+ * d_rgb + f * slab_rows * width * 12 bytes (d_hit_id / d_t: * 4 bytes); slab_rows >= hvrt_part_rows().
+ * This is what a rank of the multi-GPU batch mode runs per step: a part of one frame alone is too small a
+ * launch (its duration is set by its longest tiles, not by throughput).  No reference counterpart (the
+ * reference renders one frame at a time on one thread, OctreeLikeRayTracer.cpp:71-118).
+ *
+ * Scheduling note for both forms: each launch records the duration of every 8x8 tile, and the next launch
+ * of the same shape (image size, partition, n_frames, spp) on the same scene pulls its tiles longest-first.
+ * Only the order of work changes, never a result; HVRT_TILE_ORDER=0 in the environment disables it. */
+#define HVRT_MAX_BATCH_FRAMES 32
+int hvrt_render_batch_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frames, int n_frames,
+                                  int width, int height, int spp, uint32_t seed,
+                                  int tile_rows, int part, int n_parts, int slab_rows,
+                                  void* d_rgb, void* d_hit_id, void* d_t, void* d_counters);
 /* Rows owned by `part` (host arithmetic). */
 int hvrt_part_rows(int height, int tile_rows, int part, int n_parts);
 /* Reassembles a frame from gathered parts: d_parts holds n_parts slabs of slab_rows x width

@@ -23,7 +23,7 @@ SYMBOLS = [
     "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_set_stream", "hvrt_synchronize", "hvrt_get_timings",
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
-    "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device",
+    "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace",
 ]
 
@@ -106,6 +106,8 @@ def load_library() -> C.CDLL:
     lib.hvrt_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp]
     lib.hvrt_render_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32,
                                             C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.hvrt_render_batch_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
+                                                  C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_part_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.hvrt_assemble_parts_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.hvrt_trace.argtypes = [vp, vp, vp, C.c_uint32, vp, vp]
@@ -302,6 +304,16 @@ class Context:
         vp = lambda p: C.c_void_p(p) if p else None
         self._ck(self._lib.hvrt_render_part_device(self._h, C.byref(frame), width, height, spp, seed, tile_rows,
                                                    part, n_parts, vp(d_rgb), vp(d_hit), vp(d_t), vp(d_counters)))
+
+    def render_batch_part_device(self, frames, width: int, height: int, spp: int, seed: int,
+                                 tile_rows: int, part: int, n_parts: int, slab_rows: int,
+                                 d_rgb: int = 0, d_hit: int = 0, d_t: int = 0, d_counters: int = 0):
+        """One launch for `len(frames)` camera frames; frame f's rows go to slab f of the output buffers."""
+        vp = lambda p: C.c_void_p(p) if p else None
+        arr = (CameraFrame * len(frames))(*frames)
+        self._ck(self._lib.hvrt_render_batch_part_device(self._h, arr, len(frames), width, height, spp, seed, tile_rows,
+                                                         part, n_parts, slab_rows, vp(d_rgb), vp(d_hit), vp(d_t),
+                                                         vp(d_counters)))
 
     def assemble_parts_device(self, d_parts: int, width: int, height: int, tile_rows: int, n_parts: int,
                               slab_rows: int, bytes_per_pixel: int, d_frame: int):

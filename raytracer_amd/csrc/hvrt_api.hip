@@ -61,6 +61,22 @@ struct hvrt_ctx {
 
     // render scratch
     uint32_t* tile_counter = nullptr;
+    // camera frames of a launch: pinned staging ring -> device ring (the kernel reads them with scalar loads)
+    static constexpr int CAM_SLOTS = 4, CAM_MAX = HVRT_MAX_BATCH_FRAMES;
+    hvrt_camera_frame* cam_host = nullptr;   // CAM_SLOTS x CAM_MAX, pinned
+    hvrt_camera_frame* cam_dev = nullptr;    // CAM_SLOTS x CAM_MAX
+    hipEvent_t cam_ev[CAM_SLOTS] = {};
+    bool cam_ev_used[CAM_SLOTS] = {};
+    int cam_next = 0;
+    // longest-first tile order: per-tile durations of the previous launch of the same shape (RenderArgs)
+    uint32_t* tile_cost = nullptr;  uint64_t tile_cost_capacity = 0;
+    uint32_t* tile_order = nullptr; uint64_t tile_order_capacity = 0;
+    uint32_t* order_blocks = nullptr; uint64_t order_blocks_capacity = 0;
+    unsigned long long* cost_sum = nullptr;   // 2 x u64: this launch's and the previous launch's sum of tile costs
+    int cost_parity = 0;
+    bool adaptive_order = true;    // HVRT_TILE_ORDER=0 keeps the natural order
+    bool cost_valid = false;
+    int cost_key[8] = {};
     unsigned long long* counters = nullptr;   // 2 x u64
     void* out_buf[3] = {};  uint64_t out_cap[3] = {};   // rgb / hit / t staging for host-facing render
     void* io_buf[3] = {};   uint64_t io_cap[3] = {};    // trace staging: origins / dirs / hits
@@ -229,6 +245,12 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&c->stats, 8 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->tile_counter, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->cost_sum, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->cam_dev, sizeof(hvrt_camera_frame) * hvrt_ctx::CAM_SLOTS * hvrt_ctx::CAM_MAX)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->cam_host, sizeof(hvrt_camera_frame) * hvrt_ctx::CAM_SLOTS * hvrt_ctx::CAM_MAX, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    for (auto& ev : c->cam_ev)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_i, 2048 * 6 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
@@ -242,10 +264,12 @@ void hvrt_destroy(hvrt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
-                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters,
+                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : c->cam_ev) if (ev) (void)hipEventDestroy(ev);
+    if (c->cam_host) (void)hipHostFree(c->cam_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -287,6 +311,7 @@ static int adopt_mesh(hvrt_ctx* c, const void* src, uint32_t n_tris, hipMemcpyKi
     if (int r = ensure<float4>(c, c->tri_rec, c->rec_capacity, (uint64_t)n_tris * 3)) return r;
     c->n_tris = n_tris;
     c->has_grid = false;
+    c->cost_valid = false;
     if (n_tris) {
         HIP_TRY(c, hipMemcpyAsync(c->tri_aos, src, (size_t)n_tris * 48, kind, c->stream));
         HIP_TRY(c, launch_prepare_records(c->tri_aos, c->tri_rec, n_tris, c->stream));
@@ -356,6 +381,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     if (int r = check_grid_args(c, nx, ny, nz, mn, mx, vs)) return r;
     if (!c->tri_aos && c->n_tris) return fail(c, HVRT_ERR_INVALID, "build_grid: no mesh");
     c->has_grid = false;
+    c->cost_valid = false;
     set_grid_params(c, nx, ny, nz, mn, mx, vs);
     const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox), n_chunks = npad / SCAN_CHUNK;
 
@@ -418,6 +444,7 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
     if (!offsets || (n_refs && !indices)) return fail(c, HVRT_ERR_INVALID, "set_grid_csr: null array");
     if (n_refs > 0xFFFFFFFFull) return fail(c, HVRT_ERR_OVERFLOW, "set_grid_csr: too many references");
     c->has_grid = false;
+    c->cost_valid = false;
     set_grid_params(c, nx, ny, nz, mn, mx, vs);
     const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox);
     if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
@@ -553,33 +580,79 @@ int hvrt_part_rows(int height, int tile_rows, int part, int n_parts) {
     return rows;
 }
 
-int hvrt_render_part_device(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp,
-                            uint32_t seed, int tile_rows, int part, int n_parts, void* d_rgb, void* d_hit_id,
-                            void* d_t, void* d_counters) {
+int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_frames, int width, int height,
+                                  int spp, uint32_t seed, int tile_rows, int part, int n_parts, int slab_rows,
+                                  void* d_rgb, void* d_hit_id, void* d_t, void* d_counters) {
     if (!c) return HVRT_ERR_INVALID;
     if (int r = bind(c)) return r;
     if (int r = require_scene(c)) return r;
-    if (!frame) return fail(c, HVRT_ERR_INVALID, "render: null camera frame");
+    if (!frames) return fail(c, HVRT_ERR_INVALID, "render: null camera frame");
+    if (n_frames < 1 || n_frames > HVRT_MAX_BATCH_FRAMES)
+        return fail(c, HVRT_ERR_INVALID, "render: n_frames %d outside 1..%d", n_frames, HVRT_MAX_BATCH_FRAMES);
     if (width < 1 || height < 1 || (uint64_t)width * height > 0x7FFFFFFFull)
         return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
     if (spp < 1) return fail(c, HVRT_ERR_INVALID, "render: spp must be >= 1");
     if (tile_rows < 1 || n_parts < 1 || part < 0 || part >= n_parts)
         return fail(c, HVRT_ERR_INVALID, "render: bad partition (tile_rows %d, part %d of %d)", tile_rows, part, n_parts);
+    const int local_rows = hvrt_part_rows(height, tile_rows, part, n_parts);
+    if (slab_rows < local_rows)
+        return fail(c, HVRT_ERR_INVALID, "render: slab_rows %d < the %d rows of part %d", slab_rows, local_rows, part);
+    const uint64_t n_tiles = render_tile_count(width, local_rows, n_frames);
+    if (n_tiles > 0x7FFFFFFFull) return fail(c, HVRT_ERR_INVALID, "render: too many tiles in one launch");
+    hipStream_t s = c->stream;
+
+    // camera frames -> device (pinned staging, so the copy is asynchronous; a slot is reused only after the
+    // copy that last used it has run)
+    const int slot = c->cam_next;
+    c->cam_next = (c->cam_next + 1) % hvrt_ctx::CAM_SLOTS;
+    if (c->cam_ev_used[slot]) HIP_TRY(c, hipEventSynchronize(c->cam_ev[slot]));
+    hvrt_camera_frame* hs = c->cam_host + (size_t)slot * hvrt_ctx::CAM_MAX;
+    hvrt_camera_frame* ds = c->cam_dev + (size_t)slot * hvrt_ctx::CAM_MAX;
+    memcpy(hs, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames);
+    HIP_TRY(c, hipMemcpyAsync(ds, hs, sizeof(hvrt_camera_frame) * (size_t)n_frames, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventRecord(c->cam_ev[slot], s));
+    c->cam_ev_used[slot] = true;
+
+    // tile order: longest first, from the previous launch of the same shape
+    const int key[8] = { width, height, tile_rows, part, n_parts, n_frames, spp, 1 };
+    const bool grew = c->tile_cost_capacity < n_tiles || c->tile_order_capacity < n_tiles;
+    if (int r = ensure<uint32_t>(c, c->tile_cost, c->tile_cost_capacity, n_tiles)) return r;
+    if (int r = ensure<uint32_t>(c, c->tile_order, c->tile_order_capacity, n_tiles)) return r;
+    if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, (n_tiles + 255) / 256 + 1)) return r;
+    const bool reuse = c->adaptive_order && c->cost_valid && !grew && memcmp(key, c->cost_key, sizeof key) == 0;
+
     RenderArgs ra;
-    ra.frame = *frame;
+    ra.frames = ds; ra.n_frames = n_frames;
     ra.width = width; ra.height = height; ra.spp = spp; ra.seed = seed;
     ra.tile_rows = tile_rows; ra.part = part; ra.n_parts = n_parts;
-    ra.local_rows = hvrt_part_rows(height, tile_rows, part, n_parts);
+    ra.local_rows = local_rows; ra.slab_rows = slab_rows;
     ra.rgb = (float*)d_rgb; ra.hit_id = (uint32_t*)d_hit_id; ra.t = (float*)d_t;
     ra.counters = (unsigned long long*)d_counters;
     ra.tile_counter = c->tile_counter;
-    hipStream_t s = c->stream;
+    ra.order = reuse ? c->tile_order : nullptr;
+    ra.tile_cost = c->tile_cost;
+    unsigned long long* prev_sum = c->cost_sum + c->cost_parity;
+    c->cost_parity ^= 1;
+    ra.cost_sum = c->cost_sum + c->cost_parity;
     HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    if (reuse && n_tiles)
+        HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, prev_sum, c->order_blocks, c->tile_order, s));
     HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, s));
     HIP_TRY(c, hipEventRecord(c->ev[7], s));
+    memcpy(c->cost_key, key, sizeof key);
+    c->cost_valid = true;
     c->render_pending = true;
     return HVRT_OK;
+}
+
+int hvrt_render_part_device(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp,
+                            uint32_t seed, int tile_rows, int part, int n_parts, void* d_rgb, void* d_hit_id,
+                            void* d_t, void* d_counters) {
+    const int rows = hvrt_part_rows(height, tile_rows, part, n_parts);
+    return hvrt_render_batch_part_device(c, frame, 1, width, height, spp, seed, tile_rows, part, n_parts, rows,
+                                         d_rgb, d_hit_id, d_t, d_counters);
 }
 
 int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,

@@ -46,17 +46,26 @@ struct SceneDev {
 };
 
 struct RenderArgs {
-    hvrt_camera_frame frame;
+    const hvrt_camera_frame* frames;   // n_frames camera frames, DEVICE memory (read with scalar loads)
+    int n_frames;
     int width, height;       // full frame
     int spp;
     uint32_t seed;
     int tile_rows, part, n_parts;
     int local_rows;          // rows owned by this part
-    float* rgb;              // local_rows x width x 3 (nullable)
+    int slab_rows;           // rows between consecutive frames' outputs (>= local_rows)
+    float* rgb;              // n_frames x slab_rows x width x 3 (nullable)
     uint32_t* hit_id;        // nullable
     float* t;                // nullable
     unsigned long long* counters;  // 2 x u64, nullable
     uint32_t* tile_counter;  // persistent-thread work queue head (zeroed before launch)
+    // Work-queue order.  Slot q of the queue is tile order[q] (null: q itself); a tile is 8x8 pixels of one
+    // frame, numbered frame-major.  Every launch leaves the duration of each tile (shader clocks / 16) in
+    // tile_cost; the next launch of the same shape starts with the long tiles of this one (k_order_*), because
+    // the kernel's length is set by when its few longest tiles START, not by throughput alone.
+    const uint32_t* order;
+    uint32_t* tile_cost;
+    unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
 };
 
 // ---- launchers (hvrt_build.hip) ----
@@ -100,6 +109,11 @@ int bounds_blocks(uint64_t n_points);
 
 // ---- launchers (hvrt_trace.hip) ----
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s);
+uint64_t render_tile_count(int width, int local_rows, int n_frames);
+// order <- long tiles (cost > 2.5 x mean) first, the others behind them in natural order;
+// block_count: ceil(n_tiles / 256) + 1 u32 of scratch
+hipError_t launch_order_build(const uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum,
+                              uint32_t* block_count, uint32_t* order, hipStream_t s);
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n,
                         hvrt_hit* out, unsigned long long* counters, hipStream_t s);
 hipError_t launch_assemble(const void* parts, int width, int height, int tile_rows, int n_parts,

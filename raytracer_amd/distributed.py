@@ -193,9 +193,11 @@ class DistributedRenderer:
         self._batch += 1
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
-        for f, cam in enumerate(cam_frames):
-            self.ctx.render_part_device(cam, self.width, self.height, spp, seed, self.tile_rows, self.rank,
-                                        self.world, d_rgb=self.b_local[b][f].data_ptr())
+        # one launch for the whole batch: a part of a single frame is too small a launch (its duration is set
+        # by its longest tiles), a queue over all frames' tiles keeps the GPU at throughput
+        self.ctx.render_batch_part_device(list(cam_frames), self.width, self.height, spp, seed, self.tile_rows,
+                                          self.rank, self.world, self.part.slab_rows,
+                                          d_rgb=self.b_local[b].data_ptr())
         work = None
         if self.world > 1:
             cur.wait_event(self.stream.record_event())     # RCCL's stream orders itself after `cur`

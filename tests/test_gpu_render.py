@@ -167,6 +167,43 @@ def test_row_tile_partition_reassembles_to_the_single_gpu_frame(ctx, n_parts, ti
     assert np.array_equal(out_hit.cpu().numpy().view(np.uint32), full_hit)
 
 
+@pytest.mark.parametrize("n_parts,part,tile_rows", [(1, 0, 16), (3, 1, 8), (8, 7, 16)])
+def test_batch_launch_equals_single_launches_and_order_changes_nothing(ctx, n_parts, part, tile_rows):
+    """hvrt_render_batch_part_device: one launch for several cameras == the launches one by one, bytewise;
+    repeated launches (the 2nd and 3rd pull their tiles longest-first from the previous launch's per-tile
+    clocks) give the same bytes again."""
+    import torch
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx = setup_scene(ctx, tris, (24, 24, 24))
+    W, H = 203, 157
+    cams = [capi.make_camera_frame(*capi.default_camera(mn, mx, v)) for v in ("front", "side", "top", "front")]
+    rows = capi.part_rows(H, tile_rows, part, n_parts)
+    slab = rows + 3                                   # slabs may be padded
+    dev = torch.device("cuda:0")
+    single = torch.zeros((len(cams), slab, W, 3), dtype=torch.float32, device=dev)
+    single_hit = torch.zeros((len(cams), slab, W), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for f, cam in enumerate(cams):
+        ctx.render_part_device(cam, W, H, 1, 0, tile_rows, part, n_parts,
+                               d_rgb=single[f].data_ptr(), d_hit=single_hit[f].data_ptr())
+    ctx.synchronize()
+    want, want_hit = single.cpu().numpy(), single_hit.cpu().numpy()
+    for rep in range(3):
+        batch = torch.zeros_like(single)
+        batch_hit = torch.zeros_like(single_hit)
+        torch.cuda.synchronize()
+        ctx.render_batch_part_device(cams, W, H, 1, 0, tile_rows, part, n_parts, slab,
+                                     d_rgb=batch.data_ptr(), d_hit=batch_hit.data_ptr())
+        ctx.synchronize()
+        assert np.array_equal(batch.cpu().numpy().view(np.uint32), want.view(np.uint32)), f"rgb differs, launch {rep}"
+        assert np.array_equal(batch_hit.cpu().numpy(), want_hit), f"hit ids differ, launch {rep}"
+    with pytest.raises(capi.HvrtError):
+        ctx.render_batch_part_device(cams, W, H, 1, 0, tile_rows, part, n_parts, rows - 1 if rows else -1,
+                                     d_rgb=batch.data_ptr())
+    with pytest.raises(capi.HvrtError):
+        ctx.render_batch_part_device(cams * 9, W, H, 1, 0, tile_rows, part, n_parts, slab, d_rgb=batch.data_ptr())
+
+
 def test_render_requires_a_scene(ctx):
     ctx.set_mesh(meshgen.box())      # drops any grid
     fr = capi.make_camera_frame((0, 0, -5), (0, 0, 0), (0, 1, 0), 60.0, 4 / 3)
