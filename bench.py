@@ -193,17 +193,21 @@ def main():
         if kernel_ms:
             k_ms = float(np.mean(kernel_ms))
             achieved = bytes_per_ray * W * H / (k_ms * 1e-3) / 1e9
-            traffic = None
+            traffic, prof = None, {}
             tp = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tp):
                 try:
-                    traffic = json.load(open(tp)).get(args.workload, {}).get("k_render_hbm_bytes_per_launch")
+                    prof = json.load(open(tp)).get(args.workload, {})
+                    traffic = prof.get("k_render_hbm_bytes_per_launch")
                 except Exception:
-                    traffic = None
+                    prof, traffic = {}, None
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                                "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_render",
                                "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
-                               "note": "algorithmic (requested) bytes 8V+40T+20 per ray; >1 means cache reuse"}
+                               "note": "algorithmic (requested) bytes 8V+40T+20 per ray; >1 means the bytes are served "
+                                       "from cache or never requested; the binding resources are per-CU, see binding",
+                               "binding": {k: prof[k] for k in ("td_busy_frac", "ta_busy_frac", "valu_issue_frac", "l2_hit_rate",
+                                                                "busy_source") if k in prof}}
             nvox = g ** 3
             b_build = 72.0 * info.n_triangles + 12.0 * nvox + 20.0 * info.n_refs
             out["roofline_build"] = {"bound": "hbm", "achieved": b_build / (build_ms * 1e-3) / 1e9, "peak": 8000.0,
