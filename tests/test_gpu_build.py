@@ -204,3 +204,47 @@ def test_config2_full_size_csr(ctx):
     lo = np.clip(((t.min(1) - mn).astype(f) / f(vs)).astype(np.int32), 0, 255)
     hi = np.clip(((t.max(1) - mn).astype(f) / f(vs)).astype(np.int32), 0, 255)
     assert np.array_equal(refs, np.prod(hi - lo + 1, axis=1))
+
+
+def test_config3_like_skewed_full_size_csr(ctx):
+    """BASELINE config 3 shape: 9.8 M triangles, 8.8 M of them in a small patch, 512^3 (longest list 3706):
+    CSR and distance field compared in full."""
+    tris = meshgen.skewed_statue(289, 2100)
+    info, off, idx, mn, mx, vs = build_both(ctx, tris, (512, 512, 512))
+    assert info.max_list > 1000 and info.n_refs > 15_000_000
+
+
+def test_config5_full_size_csr(ctx):
+    """BASELINE config 5: 49 988 172 triangles into 1024^3 (build only).  Offsets (4.3 GB) and indices compared
+    bit for bit with the oracle; the distance field checked through the property that defines it: 0 exactly
+    on occupied voxels, elsewhere 1 + the smallest of the six neighbours (saturating at 255)."""
+    g = 1024
+    tris = meshgen.cube_sphere(2041)
+    assert tris.shape[0] == 49_988_172
+    ctx.set_mesh(tris)
+    mn, mx = ctx.mesh_bounds()
+    vs = capi.voxel_size(mn, mx, g, g, g)
+    info = ctx.build_grid(g, g, g, mn, mx, vs)
+    off, idx = ctx.get_csr()
+    ooff, oidx = oracle.voxelize(tris, g, g, g, mn, vs)
+    del tris
+    assert info.n_refs == oidx.size
+    assert np.array_equal(idx, oidx), "CSR indices differ"
+    del idx, oidx
+    assert np.array_equal(off, ooff), "CSR offsets differ"
+    del ooff
+    occ = (off[1:] != off[:-1]).reshape(g, g, g)
+    del off
+    assert info.n_occupied == int(occ.sum())
+    d = ctx.distance_field()
+    assert np.array_equal(d == 0, occ)
+    del occ
+    m = np.full(d.shape, 255, np.uint8)
+    for ax in range(3):
+        lo = [slice(None)] * 3; hi = [slice(None)] * 3
+        lo[ax], hi[ax] = slice(0, g - 1), slice(1, g)
+        np.minimum(m[tuple(hi)], d[tuple(lo)], out=m[tuple(hi)])
+        np.minimum(m[tuple(lo)], d[tuple(hi)], out=m[tuple(lo)])
+    want = np.where(m == 255, 255, m + 1).astype(np.uint8)
+    free = d != 0
+    assert np.array_equal(d[free], want[free])

@@ -251,6 +251,49 @@ def test_config2_full_size_render_rows(ctx):
     assert np.array_equal(np.broadcast_to(bg, (H, W))[~m], rgb[..., 0][~m])
 
 
+def _rows_against_oracle(ctx, tris, g, W, H, rows, spp=1, seed=0, launches=1):
+    ctx.set_mesh(tris)
+    mn, mx = ctx.mesh_bounds()
+    vs = capi.voxel_size(mn, mx, g, g, g)
+    ctx.build_grid(g, g, g, mn, mx, vs)
+    off, idx = ctx.get_csr()
+    sc = oracle.OracleScene(tris, g, g, g, mn, vs, off, idx)
+    fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
+    for _ in range(launches):            # later launches pull their tiles in the order the first one measured
+        rgb, hit, t, cnt = ctx.render(fr, W, H, spp=spp, seed=seed)
+    ohit = np.zeros((len(rows), W), np.uint32)
+    ot = np.zeros((len(rows), W), np.float32)
+    orgb = np.zeros((len(rows), W, 3), np.float32)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def band(k):
+        r = sc.render(fr, W, H, threads=1, rows=(rows[k], rows[k] + 1), spp=spp, seed=seed)
+        orgb[k], ohit[k], ot[k] = r[0][rows[k]], r[1][rows[k]], r[2][rows[k]]
+
+    with ThreadPoolExecutor(16) as ex:
+        list(ex.map(band, range(len(rows))))
+    assert np.array_equal(hit[rows], ohit)
+    assert np.array_equal(t[rows].view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(rgb[rows].view(np.uint32), orgb.view(np.uint32))
+    return rgb, hit, t
+
+
+def test_config3_like_full_size_render_rows(ctx):
+    """BASELINE config 3 shape (9.8 M triangles, dense patch with 3706-entry lists, 512^3, 3840x2160): every
+    24th row, and every 2nd row across the patch, bit for bit against the oracle; second launch (ordered)."""
+    W, H = 3840, 2160
+    rows = sorted(set(range(0, H, 24)) | set(range(1000, 1160, 2)))
+    _rows_against_oracle(ctx, meshgen.skewed_statue(289, 2100), 512, W, H, rows, launches=2)
+
+
+def test_config4_8k_16spp_rows(ctx):
+    """BASELINE config 4: the config 2 scene at 7680x4320 with 16 jittered samples per pixel; 24 rows against
+    the oracle (colour is the mean of 16 samples summed in sample order; hit id / t are sample 0's)."""
+    W, H = 7680, 4320
+    rows = list(range(7, H, 180))
+    _rows_against_oracle(ctx, meshgen.cube_sphere(289), 256, W, H, rows, spp=16, seed=1)
+
+
 @pytest.mark.parametrize("name", ["sphere_16", "slivers", "skewed_long_lists"])
 def test_render_from_an_ingested_cpu_grid(ctx, name):
     """IRayTracer's constructor path: the CSR comes from the CPU (hvrt_set_grid_csr); the skip bits are
