@@ -210,6 +210,19 @@ int hvrt_render_batch_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frames
                                   int width, int height, int spp, uint32_t seed,
                                   int tile_rows, int part, int n_parts, int slab_rows,
                                   void* d_rgb, void* d_hit_id, void* d_t, void* d_counters);
+
+/* Replaces: the per-channel conversion loop of saveToPPM / saveToJPG / saveToPNG (ImageSaver.h:28-33, 48-52,
+ * 67-71): byte = (uint8_t)clamp(c * 255.0f, 0.0f, 255.0f), truncating; done on the device so that 3 bytes per
+ * pixel leave the GPU instead of 12.  n_values = pixels * 3.  d_rgb 16-byte aligned, d_rgb8 4-byte aligned.
+ * Asynchronous on the context's stream. */
+int hvrt_quantise_rgb8_device(hvrt_ctx* ctx, const void* d_rgb, uint64_t n_values, void* d_rgb8);
+
+/* Replaces: the three render + save passes of TraceImageMultiView (TraceImages.cpp:77-119) up to the image
+ * encoder: n_frames views of the resident scene in ONE launch, quantised on the device, returned as 8-bit
+ * RGB (frame-major, rows bottom-up as the reference's framebuffer).  hit_id (n_frames x H x W, nullable) and
+ * counters (nullable) as for hvrt_render.  Synchronous. */
+int hvrt_render_views_rgb8(hvrt_ctx* ctx, const hvrt_camera_frame* frames, int n_frames, int width, int height,
+                           uint8_t* rgb8, uint32_t* hit_id, uint64_t counters[2]);
 /* Rows owned by `part` (host arithmetic). */
 int hvrt_part_rows(int height, int tile_rows, int part, int n_parts);
 /* Reassembles a frame from gathered parts: d_parts holds n_parts slabs of slab_rows x width

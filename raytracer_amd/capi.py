@@ -23,7 +23,7 @@ SYMBOLS = [
     "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_set_stream", "hvrt_synchronize", "hvrt_get_timings",
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
-    "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device",
+    "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace",
 ]
 
@@ -108,6 +108,8 @@ def load_library() -> C.CDLL:
                                             C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_render_batch_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                                   C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.hvrt_quantise_rgb8_device.argtypes = [vp, vp, C.c_uint64, vp]
+    lib.hvrt_render_views_rgb8.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, vp, vp, vp]
     lib.hvrt_part_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.hvrt_assemble_parts_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.hvrt_trace.argtypes = [vp, vp, vp, C.c_uint32, vp, vp]
@@ -314,6 +316,19 @@ class Context:
         self._ck(self._lib.hvrt_render_batch_part_device(self._h, arr, len(frames), width, height, spp, seed, tile_rows,
                                                          part, n_parts, slab_rows, vp(d_rgb), vp(d_hit), vp(d_t),
                                                          vp(d_counters)))
+
+    def quantise_rgb8_device(self, d_rgb: int, n_values: int, d_rgb8: int):
+        self._ck(self._lib.hvrt_quantise_rgb8_device(self._h, C.c_void_p(d_rgb), n_values, C.c_void_p(d_rgb8)))
+
+    def render_views_rgb8(self, frames, width: int, height: int, want_hit=True):
+        """len(frames) views in one launch -> (n, H, W, 3) uint8 (+ (n, H, W) uint32 hit ids, counters)."""
+        n = len(frames)
+        arr = (CameraFrame * n)(*frames)
+        rgb8 = np.empty((n, height, width, 3), np.uint8)
+        hit = np.empty((n, height, width), np.uint32) if want_hit else None
+        cnt = np.zeros(2, np.uint64)
+        self._ck(self._lib.hvrt_render_views_rgb8(self._h, arr, n, width, height, _ptr(rgb8), _ptr(hit), _ptr(cnt)))
+        return rgb8, hit, cnt
 
     def assemble_parts_device(self, d_parts: int, width: int, height: int, tile_rows: int, n_parts: int,
                               slab_rows: int, bytes_per_pixel: int, d_frame: int):

@@ -679,6 +679,44 @@ int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int heig
     return HVRT_OK;
 }
 
+int hvrt_quantise_rgb8_device(hvrt_ctx* c, const void* d_rgb, uint64_t n_values, void* d_rgb8) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (n_values && (!d_rgb || !d_rgb8)) return fail(c, HVRT_ERR_INVALID, "quantise: null pointer");
+    if (((uintptr_t)d_rgb & 15) || ((uintptr_t)d_rgb8 & 3)) return fail(c, HVRT_ERR_INVALID, "quantise: d_rgb must be 16-byte and d_rgb8 4-byte aligned");
+    HIP_TRY(c, launch_quantise_rgb8((const float*)d_rgb, n_values, (uint8_t*)d_rgb8, c->stream));
+    return HVRT_OK;
+}
+
+int hvrt_render_views_rgb8(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_frames, int width, int height,
+                           uint8_t* rgb8, uint32_t* hit_id, uint64_t counters[2]) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (width < 1 || height < 1) return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
+    if (n_frames < 1 || n_frames > HVRT_MAX_BATCH_FRAMES)
+        return fail(c, HVRT_ERR_INVALID, "render: n_frames %d outside 1..%d", n_frames, HVRT_MAX_BATCH_FRAMES);
+    if (!rgb8) return fail(c, HVRT_ERR_INVALID, "render: null output");
+    const uint64_t npx = (uint64_t)width * height * (uint64_t)n_frames;
+    // float frames and their bytes share the first staging buffer (bytes behind the floats, 16-B aligned)
+    const uint64_t f_bytes = (npx * 12 + 15) / 16 * 16;
+    if (int r = ensure_bytes(c, c->out_buf[0], c->out_cap[0], f_bytes + npx * 3 + 16)) return r;
+    if (hit_id) if (int r = ensure_bytes(c, c->out_buf[1], c->out_cap[1], npx * 4)) return r;
+    hipStream_t s = c->stream;
+    if (counters) HIP_TRY(c, hipMemsetAsync(c->counters, 0, 16, s));
+    if (int r = hvrt_render_batch_part_device(c, frames, n_frames, width, height, 1, 0, height, 0, 1, height,
+                                              c->out_buf[0], hit_id ? c->out_buf[1] : nullptr, nullptr,
+                                              counters ? c->counters : nullptr)) return r;
+    uint8_t* d8 = (uint8_t*)c->out_buf[0] + f_bytes;
+    HIP_TRY(c, launch_quantise_rgb8((const float*)c->out_buf[0], npx * 3, d8, s));
+    HIP_TRY(c, hipMemcpyAsync(rgb8, d8, npx * 3, hipMemcpyDeviceToHost, s));
+    if (hit_id) HIP_TRY(c, hipMemcpyAsync(hit_id, c->out_buf[1], npx * 4, hipMemcpyDeviceToHost, s));
+    if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->tm.render_ms = ms_between(c->ev[6], c->ev[7]);
+    c->render_pending = false;
+    return HVRT_OK;
+}
+
 int hvrt_assemble_parts_device(hvrt_ctx* c, const void* d_parts, int width, int height, int tile_rows, int n_parts,
                                int slab_rows, int bytes_per_pixel, void* d_frame) {
     if (!c) return HVRT_ERR_INVALID;

@@ -116,6 +116,7 @@ hipError_t launch_order_build(const uint32_t* tile_cost, uint32_t n_tiles, const
                               uint32_t* block_count, uint32_t* order, hipStream_t s);
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n,
                         hvrt_hit* out, unsigned long long* counters, hipStream_t s);
+hipError_t launch_quantise_rgb8(const float* rgb /* 16-B aligned */, uint64_t n_values, uint8_t* out /* 4-B aligned */, hipStream_t s);
 hipError_t launch_assemble(const void* parts, int width, int height, int tile_rows, int n_parts,
                            int slab_rows, int bytes_per_pixel, void* frame, hipStream_t s);
 

@@ -445,6 +445,24 @@ __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const float* __restr
     }
 }
 
+// ImageSaver.h:18-75: byte = static_cast<uint8_t>(std::clamp(c * 255.0f, 0.0f, 255.0f)) -- truncation; a NaN
+// passes std::clamp unchanged and its conversion is undefined there (0 on the reference's platform): 0 here.
+__device__ __forceinline__ uint32_t quantise_channel(float c) {
+    const float v = c * 255.0f;
+    const float k = v < 0.0f ? 0.0f : (255.0f < v ? 255.0f : v);
+    return k == k ? (uint32_t)(int)k : 0u;
+}
+__global__ __launch_bounds__(256) void k_quantise_rgb8(const float* __restrict__ rgb, uint64_t n, uint8_t* __restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;     // four channels -> one dword
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(rgb + i);
+        *reinterpret_cast<uint32_t*>(out + i) = quantise_channel(v.x) | (quantise_channel(v.y) << 8) |
+                                                (quantise_channel(v.z) << 16) | (quantise_channel(v.w) << 24);
+    } else {
+        for (uint64_t k = i; k < n; ++k) out[k] = (uint8_t)quantise_channel(rgb[k]);
+    }
+}
+
 // frame[y][x] <- parts[part(y)][local_row(y)][x], 4-byte words
 __global__ __launch_bounds__(256) void k_assemble(const uint32_t* __restrict__ parts, int words_per_row, int height,
                                                   int tile_rows, int n_parts, int slab_rows,
@@ -492,6 +510,12 @@ hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* d
     if (n == 0) return hipSuccess;
     if (sc.ref_rec) k_trace<true><<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
     else k_trace<false><<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantise_rgb8(const float* rgb, uint64_t n_values, uint8_t* out, hipStream_t s) {
+    if (n_values == 0) return hipSuccess;
+    k_quantise_rgb8<<<(unsigned)((n_values + 1023) / 1024), 256, 0, s>>>(rgb, n_values, out);
     return hipGetLastError();
 }
 

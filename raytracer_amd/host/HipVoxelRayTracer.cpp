@@ -142,6 +142,31 @@ std::vector<Vec3> HipVoxelRayTracer::render(const Camera& cam, int width, int he
     return frame;
 }
 
+std::vector<std::vector<unsigned char>> HipVoxelRayTracer::renderViewsRgb8(const std::vector<Camera>& cams, int width, int height) {
+    if (width <= 0 || height <= 0) throw std::runtime_error("render: width and height must be positive");
+    if (cams.empty()) return {};
+    std::vector<hvrt_camera_frame> fr(cams.size());
+    for (size_t i = 0; i < cams.size(); ++i)
+        hvrt_make_camera_frame(&cams[i].position.x, &cams[i].lookAt.x, &cams[i].up.x, cams[i].fov, cams[i].aspectRatio, &fr[i]);
+    const size_t npx = (size_t)width * height;
+    std::vector<unsigned char> all(npx * 3 * cams.size());
+    std::vector<unsigned int> hits(npx * cams.size());
+    uint64_t counters[2] = { 0, 0 };
+    LOG_INFO("[{}] Rendering {} views of {}x{} in one launch...", getMethodName(), cams.size(), width, height);
+    ck(scene_->handle(), hvrt_render_views_rgb8(scene_->handle(), fr.data(), (int)fr.size(), width, height, all.data(),
+                                                hits.data(), counters), "hvrt_render_views_rgb8");
+    voxels_ = counters[0];
+    tests_ = counters[1];
+    hit_ids_.assign(hits.end() - (std::ptrdiff_t)npx, hits.end());
+    const double total = (double)npx * cams.size();
+    LOG_INFO("[{}] Rendering complete! kernel {:.3f} ms", getMethodName(), scene_->lastRenderMs());
+    LOG_INFO("[{}] Voxels traversed: {}, Avg per ray: {:.1f}", getMethodName(), voxels_, voxels_ / total);
+    LOG_INFO("[{}] Triangle tests: {}, Avg per ray: {:.1f}", getMethodName(), tests_, tests_ / total);
+    std::vector<std::vector<unsigned char>> out(cams.size());
+    for (size_t i = 0; i < cams.size(); ++i) out[i].assign(all.begin() + (std::ptrdiff_t)(i * npx * 3), all.begin() + (std::ptrdiff_t)((i + 1) * npx * 3));
+    return out;
+}
+
 std::vector<RayHit> HipVoxelRayTracer::traceRays(const std::vector<Ray>& rays) {
     const size_t n = rays.size();
     std::vector<float> o(3 * n), d(3 * n);

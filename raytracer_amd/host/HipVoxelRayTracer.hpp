@@ -56,6 +56,12 @@ public:
     cg_datastructures::RayHit traceRay(const cg_datastructures::Ray& ray) override;
     std::string getMethodName() const override { return "HipVoxelGrid"; }
 
+    // Several views of the resident scene in ONE launch, quantised to 8-bit RGB on the GPU
+    // (ImageSaver.h's conversion): what TraceImageMultiView needs, at 3 bytes per pixel over PCIe.
+    // Returns cameras.size() frames of width*height*3 bytes, rows bottom-up like render().
+    std::vector<std::vector<unsigned char>> renderViewsRgb8(const std::vector<cg_datastructures::Camera>& cameras,
+                                                            int width, int height);
+
     // Batched traceRay and the statistics the reference logs (OctreeLikeRayTracer.cpp:57-65).
     std::vector<cg_datastructures::RayHit> traceRays(const std::vector<cg_datastructures::Ray>& rays);
     unsigned long long voxelsTraversed() const { return voxels_; }

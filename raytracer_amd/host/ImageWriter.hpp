@@ -24,13 +24,16 @@ inline std::vector<uint8_t> quantise(const std::vector<Vec3>& px) {
     return out;
 }
 
-inline bool saveToPPM(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
+// 8-bit RGB in, as hvrt_render_views_rgb8 / hvrt_quantise_rgb8_device deliver it (quantised on the GPU)
+inline bool saveBytesToPPM(const std::string& filename, const uint8_t* q, int width, int height) {
     std::ofstream f(filename, std::ios::binary);
     if (!f) return false;
     f << "P6\n" << width << " " << height << "\n255\n";
-    std::vector<uint8_t> q = quantise(pixels);
-    f.write(reinterpret_cast<const char*>(q.data()), (std::streamsize)q.size());
+    f.write(reinterpret_cast<const char*>(q), (std::streamsize)((size_t)width * height * 3));
     return (bool)f;
+}
+inline bool saveToPPM(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
+    return saveBytesToPPM(filename, quantise(pixels).data(), width, height);
 }
 
 namespace png_detail {
@@ -63,7 +66,7 @@ inline void chunk(std::ofstream& f, const char* type, const std::vector<uint8_t>
 }
 }  // namespace png_detail
 
-inline bool saveToPNG(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
+inline bool saveBytesToPNG(const std::string& filename, const uint8_t* q, int width, int height) {
     using namespace png_detail;
     std::ofstream f(filename, std::ios::binary);
     if (!f) return false;
@@ -74,11 +77,11 @@ inline bool saveToPNG(const std::string& filename, const std::vector<Vec3>& pixe
     be32(ihdr, (uint32_t)height);
     ihdr.insert(ihdr.end(), { 8, 2, 0, 0, 0 });   // 8-bit RGB
     chunk(f, "IHDR", ihdr);
-    std::vector<uint8_t> q = quantise(pixels), raw;
+    std::vector<uint8_t> raw;
     raw.reserve(((size_t)width * 3 + 1) * height);
     for (int y = 0; y < height; ++y) {
         raw.push_back(0);   // filter: none
-        raw.insert(raw.end(), q.begin() + (size_t)y * width * 3, q.begin() + (size_t)(y + 1) * width * 3);
+        raw.insert(raw.end(), q + (size_t)y * width * 3, q + (size_t)(y + 1) * width * 3);
     }
     std::vector<uint8_t> z = { 0x78, 0x01 };
     uint32_t a = 1, b = 0;   // adler32
@@ -96,6 +99,9 @@ inline bool saveToPNG(const std::string& filename, const std::vector<Vec3>& pixe
     chunk(f, "IDAT", z);
     chunk(f, "IEND", {});
     return (bool)f;
+}
+inline bool saveToPNG(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
+    return saveBytesToPNG(filename, quantise(pixels).data(), width, height);
 }
 
 }  // namespace cg_datastructures

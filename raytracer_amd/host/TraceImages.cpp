@@ -153,16 +153,35 @@ void TraceImages::TraceImageMultiView(std::string gridFileLocation, std::string 
         const fs::path base(baseOutputName);
         const std::string ext = base.extension().string(), stem = base.stem().string();
         const std::pair<CameraView, const char*> views[] = { { CameraView::FRONT, "_front" }, { CameraView::SIDE, "_side" }, { CameraView::TOP, "_top" } };
-        for (const auto& [view, suffix] : views) {
-            auto tv = std::chrono::steady_clock::now();
-            renderAndSave(l, setupCameraWithView(l.grid, view), stem + suffix + ext, method);
-            LOG_INFO("View rendered in {:.3f}s", seconds_since(tv));
-        }
+        // one launch for the three views, quantised on the GPU: 3 bytes per pixel come back
+        std::vector<Camera> cams;
+        for (const auto& vs : views) cams.push_back(setupCameraWithView(l.grid, vs.first));
+        HipVoxelRayTracer tracer(l.scene);
+        auto tv = std::chrono::steady_clock::now();
+        const auto frames = tracer.renderViewsRgb8(cams, imageWidth, imageHeight);
+        lastPixels.clear();
+        lastHitIds = tracer.lastHitIds();
+        LOG_INFO("{} views rendered in {:.3f}s", frames.size(), seconds_since(tv));
+        for (size_t i = 0; i < frames.size(); ++i)
+            SaveImageBytes(outputDirectory + stem + views[i].second + ext, frames[i].data(), imageWidth, imageHeight);
         LOG_INFO("Success! Generated all views in {:.3f}s", seconds_since(t0));
         lastOk = true;
     } catch (const std::exception& e) {
         LOG_ERROR("Failed: {} - {} (after {:.3f}s)", gridFileLocation, e.what(), seconds_since(t0));
     }
+}
+
+void TraceImages::SaveImageBytes(const std::string& filename, const unsigned char* rgb8, int width, int height) {
+    const fs::path p(filename);
+    if (!p.parent_path().empty() && !fs::exists(p.parent_path())) fs::create_directories(p.parent_path());
+    const std::string ext = lower_ext(filename);
+    bool ok;
+    if (ext == ".png") ok = saveBytesToPNG(filename, rgb8, width, height);
+    else {
+        if (ext != ".ppm") LOG_WARN("Extension '{}' is written as PPM bytes by this library", ext);
+        ok = saveBytesToPPM(filename, rgb8, width, height);
+    }
+    if (ok) LOG_INFO("Image saved: {}", filename); else LOG_ERROR("Failed to save: {}", filename);
 }
 
 void TraceImages::SaveImage(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {

@@ -62,4 +62,5 @@ private:
     Loaded loadOrGenerate(const std::string& path, int nx, int ny, int nz, RayTracingMethod method);
     void renderAndSave(Loaded& l, const cg_datastructures::Camera& cam, const std::string& filename, RayTracingMethod method);
     void SaveImage(const std::string& filename, const std::vector<cg_datastructures::Vec3>& pixels, int width, int height);
+    void SaveImageBytes(const std::string& filename, const unsigned char* rgb8, int width, int height);
 };

@@ -204,6 +204,40 @@ def test_batch_launch_equals_single_launches_and_order_changes_nothing(ctx, n_pa
         ctx.render_batch_part_device(cams * 9, W, H, 1, 0, tile_rows, part, n_parts, slab, d_rgb=batch.data_ptr())
 
 
+def _quantise_ref(rgb):
+    """ImageSaver.h:28-33: (uint8_t)clamp(c * 255.0f, 0.0f, 255.0f), truncating; NaN -> 0 (documented)."""
+    v = rgb.astype(np.float32) * np.float32(255.0)
+    k = np.where(v < 0, np.float32(0), np.where(v > 255, np.float32(255), v))
+    return np.where(np.isnan(k), 0, k).astype(np.int32).astype(np.uint8)
+
+
+def test_views_rgb8_is_the_float_frames_quantised_like_the_reference(ctx):
+    import torch
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx = setup_scene(ctx, tris, (24, 24, 24))
+    W, H = 203, 157
+    cams = [capi.make_camera_frame(*capi.default_camera(mn, mx, v)) for v in ("front", "side", "top")]
+    rgb8, hit, cnt = ctx.render_views_rgb8(cams, W, H)
+    tot = np.zeros(2, np.uint64)
+    for f, cam in enumerate(cams):
+        rgb, h, t, c = ctx.render(cam, W, H)
+        assert np.array_equal(rgb8[f], _quantise_ref(rgb)), f"view {f}"
+        assert np.array_equal(hit[f], h)
+        tot += c
+    assert np.array_equal(cnt, tot)
+    # the device conversion on awkward values and a length that is not a multiple of 4
+    vals = np.array([-1.0, -0.0, 0.0, 0.0039, 0.00393, 0.5, 0.999, 1.0, 1.1, 300.0, np.nan, np.inf, -np.inf, 1e-40,
+                     0.1 + 0.9, 254.9999 / 255.0, 255.0 / 255.0], np.float32)
+    vals = np.concatenate([vals, np.random.default_rng(5).random(1000).astype(np.float32) * 1.2 - 0.1])[:1015]
+    d_in = torch.from_numpy(vals).to("cuda:0")
+    d_out = torch.zeros(vals.size + 1, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.quantise_rgb8_device(d_in.data_ptr(), vals.size, d_out.data_ptr())
+    ctx.synchronize()
+    got = d_out.cpu().numpy()
+    assert np.array_equal(got[:-1], _quantise_ref(vals)) and got[-1] == 0
+
+
 def test_render_requires_a_scene(ctx):
     ctx.set_mesh(meshgen.box())      # drops any grid
     fr = capi.make_camera_frame((0, 0, -5), (0, 0, 0), (0, 1, 0), 60.0, 4 / 3)
