@@ -237,6 +237,12 @@ int hvrt_assemble_parts_device(hvrt_ctx* ctx, const void* d_parts, int width, in
 int hvrt_trace(hvrt_ctx* ctx, const float* origins, const float* dirs, uint32_t n,
                hvrt_hit* out, uint64_t counters[2]);
 
+/* Device-resident form of hvrt_trace (rays produced on the GPU, e.g. by a caller's own camera or secondary-ray
+ * kernel): d_origins / d_dirs n x 3 floats, d_hits n x hvrt_hit, d_counters 2 x u64 accumulated into (nullable).
+ * Asynchronous on the context's stream; its kernel time is reported as render_ms after hvrt_synchronize. */
+int hvrt_trace_device(hvrt_ctx* ctx, const void* d_origins, const void* d_dirs, uint32_t n,
+                      void* d_hits, void* d_counters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,7 @@ SYMBOLS = [
     "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_set_stream", "hvrt_synchronize", "hvrt_get_timings",
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
-    "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8",
+    "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace",
 ]
 
@@ -113,6 +113,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_part_rows.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
     lib.hvrt_assemble_parts_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp]
     lib.hvrt_trace.argtypes = [vp, vp, vp, C.c_uint32, vp, vp]
+    lib.hvrt_trace_device.argtypes = [vp, vp, vp, C.c_uint32, vp, vp]
     _lib = lib
     return lib
 
@@ -334,6 +335,10 @@ class Context:
                               slab_rows: int, bytes_per_pixel: int, d_frame: int):
         self._ck(self._lib.hvrt_assemble_parts_device(self._h, C.c_void_p(d_parts), width, height, tile_rows,
                                                       n_parts, slab_rows, bytes_per_pixel, C.c_void_p(d_frame)))
+
+    def trace_device(self, d_origins: int, d_dirs: int, n: int, d_hits: int, d_counters: int = 0):
+        self._ck(self._lib.hvrt_trace_device(self._h, C.c_void_p(d_origins), C.c_void_p(d_dirs), n, C.c_void_p(d_hits),
+                                             C.c_void_p(d_counters) if d_counters else None))
 
     def trace(self, origins: np.ndarray, dirs: np.ndarray, want_counters=True):
         o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)

@@ -756,4 +756,19 @@ int hvrt_trace(hvrt_ctx* c, const float* origins, const float* dirs, uint32_t n,
     return HVRT_OK;
 }
 
+int hvrt_trace_device(hvrt_ctx* c, const void* d_origins, const void* d_dirs, uint32_t n, void* d_hits, void* d_counters) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (int r = require_scene(c)) return r;
+    if (n && (!d_origins || !d_dirs || !d_hits)) return fail(c, HVRT_ERR_INVALID, "trace: null pointer");
+    if (!n) return HVRT_OK;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    HIP_TRY(c, launch_trace(scene_of(c), (const float*)d_origins, (const float*)d_dirs, n, (hvrt_hit*)d_hits,
+                            (unsigned long long*)d_counters, s));
+    HIP_TRY(c, hipEventRecord(c->ev[7], s));
+    c->render_pending = true;      // hvrt_synchronize reads the pair of events into render_ms
+    return HVRT_OK;
+}
+
 }  // extern "C"

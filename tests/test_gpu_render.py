@@ -122,6 +122,17 @@ def test_trace_ray_batch(ctx):
     assert 0 < got["hit"].sum() < n
     miss = got["hit"] == 0
     assert np.all(got["t"][miss] == np.finfo(np.float32).max) and np.all(got["triangle_index"][miss] == 0)
+    # device-resident form: same records, same counters
+    import torch
+    d_o, d_d = torch.from_numpy(o).to("cuda:0"), torch.from_numpy(d).to("cuda:0")
+    d_h = torch.zeros(n * capi.HIT_DTYPE.itemsize, dtype=torch.uint8, device="cuda:0")
+    d_c = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    ctx.trace_device(d_o.data_ptr(), d_d.data_ptr(), n, d_h.data_ptr(), d_c.data_ptr())
+    ctx.synchronize()
+    dev = d_h.cpu().numpy().view(capi.HIT_DTYPE)
+    assert dev.tobytes() == got.tobytes()
+    assert np.array_equal(d_c.cpu().numpy().astype(np.uint64), gcnt)
 
 
 def test_jittered_supersampling_extension(ctx):
