@@ -76,15 +76,15 @@ typedef struct hvrt_grid_info {
 } hvrt_grid_info;
 
 /* Per-call device timings (HIP events on the context's stream), milliseconds.
- * build_total_ms = count + scan + fill + order + expand. */
+ * build_total_ms = count + scan + fill + sort + expand. */
 typedef struct hvrt_timings {
-    float build_total_ms;   /* hvrt_build_grid: count + scan + fill + order */
+    float build_total_ms;   /* hvrt_build_grid, everything */
     float build_count_ms;
     float build_scan_ms;
     float build_fill_ms;
     float build_sort_ms;
-    float build_expand_ms;  /* per-reference traversal records (libhvrt's own acceleration data) */
-    float render_ms;        /* last hvrt_render* traversal kernel(s) */
+    float build_expand_ms;  /* libhvrt's own acceleration data: distance field, face bits, per-reference records */
+    float render_ms;        /* last hvrt_render* / hvrt_trace_device: tile ordering + traversal kernel */
     float trace_ms;         /* last hvrt_trace */
 } hvrt_timings;
 
