@@ -241,39 +241,56 @@ __global__ __launch_bounds__(256) void k_scan_reduce(const uint4* __restrict__ c
     }
 }
 
-// phase B: exclusive scan of the chunk sums by one workgroup
+// phase B: exclusive scan of the chunk sums by one workgroup.  Each of the 16 waves owns a contiguous run of
+// sums and walks it in rows of 64 (one coalesced 512-byte read per row): wave scan per row, carry between
+// rows; the 16 run totals meet once in LDS.  The per-chunk (occupied, longest) pairs are folded on the way.
+__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
 __global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ block_sums, uint64_t n,
                                                     uint64_t* __restrict__ stats) {
-    __shared__ uint64_t s[1024];
-    const uint64_t per = (n + 1023) / 1024;
-    const uint64_t b = threadIdx.x * per;
+    __shared__ uint64_t s_tot[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t per = ((n + 15) / 16 + 63) / 64 * 64;          // run length per wave, whole rows
+    const uint64_t b = (uint64_t)w * per;
     const uint64_t e = b + per < n ? b + per : n;
-    uint64_t sum = 0, occ = 0;
+    uint64_t occ = 0, total = 0;
     uint32_t mx = 0;
-    for (uint64_t i = b; i < e; ++i) {
-        sum += block_sums[i];
-        const uint64_t aux = block_sums[n + i];
-        occ += aux & 0xFFFFFFFFull;
-        const uint32_t m = (uint32_t)(aux >> 32);
-        mx = m > mx ? m : mx;
+    for (uint64_t r = b; r < e; r += 64) {                        // pass 1: run total, occupancy, longest list
+        const uint64_t i = r + lane;
+        if (i < e) {
+            total += block_sums[i];
+            const uint64_t aux = block_sums[n + i];
+            occ += aux & 0xFFFFFFFFull;
+            const uint32_t m = (uint32_t)(aux >> 32);
+            mx = m > mx ? m : mx;
+        }
     }
+    total = wave_sum64(total);
     occ = wave_sum64(occ);
     mx = wave_max32(mx);
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
+        s_tot[w] = total;
         if (occ) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)occ);
         if (mx) atomicMax((unsigned long long*)&stats[2], (unsigned long long)mx);
     }
-    s[threadIdx.x] = sum;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint64_t o = threadIdx.x >= (unsigned)d ? s[threadIdx.x - d] : 0;
-        __syncthreads();
-        s[threadIdx.x] += o;
-        __syncthreads();
+    uint64_t carry = 0;
+    for (int k = 0; k < w; ++k) carry += s_tot[k];
+    if (threadIdx.x == 1023) { uint64_t t = 0; for (int k = 0; k < 16; ++k) t += s_tot[k]; stats[0] = t; }
+    for (uint64_t r = b; r < e; r += 64) {                        // pass 2: exclusive prefixes, in place
+        const uint64_t i = r + lane;
+        const uint64_t v = i < e ? block_sums[i] : 0;
+        const uint64_t inc = wave_inclusive_scan64(v);
+        if (i < e) block_sums[i] = carry + inc - v;
+        carry += __shfl(inc, 63);
     }
-    uint64_t run = s[threadIdx.x] - sum;
-    for (uint64_t i = b; i < e; ++i) { uint64_t v = block_sums[i]; block_sums[i] = run; run += v; }
-    if (threadIdx.x == 1023) stats[0] = s[1023];
 }
 
 // phase C: per-chunk exclusive scan, in place.  Each wave owns 1024 consecutive counters and walks them in
