@@ -69,18 +69,6 @@ struct RenderArgs {
 };
 
 // ---- launchers (hvrt_build.hip) ----
-struct BuildScratch {
-    uint32_t* cnt_base;        // nvox_padded + 8 u32
-    uint64_t cnt_capacity;     // in u32
-    uint32_t* ranges;          // T x 3 u32 (lo | hi << 16 per axis)
-    uint64_t ranges_capacity;  // in triangles
-    uint64_t* block_sums;      // scan partials
-    uint64_t block_sums_capacity;
-    uint64_t* stats;           // [0]=total refs, [1]=occupied, [2]=max list, [3]=long-queue length
-    uint32_t* long_queue;
-    uint64_t long_queue_capacity;
-};
-
 constexpr int SCAN_CHUNK = 4096;  // elements per scan block (256 threads x 16)
 
 hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t n_tris, hipStream_t s);
