@@ -20,6 +20,9 @@ struct hvrt_ctx {
     int n_cus = 256;
     hipStream_t stream = nullptr;       // the stream all work is issued on (own_stream unless hvrt_set_stream)
     hipStream_t own_stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // the distance field is built here, beside sort / face bits / records
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool dist_in_flight = false;
     hipEvent_t ev[10] = {};
     std::string error;
 
@@ -174,10 +177,28 @@ int require_scene(hvrt_ctx* c) {
 
 // Builds the per-reference records (and validates every CSR index against the mesh).  Falls back to the
 // indexed traversal when switched off or when the array does not fit in device memory.
-int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate) {
-    c->ref_rec_valid = false;
+// The distance field needs only the finished offsets, so it runs on a second stream beside the kernels that
+// order the lists and derive face bits and records (small grids: those kernels are a few waves each and
+// overlap almost entirely).  fork after the offsets are final, join before the build returns.
+int fork_distance_field(hvrt_ctx* c, hipStream_t s) {
     if (int r = ensure<uint8_t>(c, c->dist, c->dist_capacity, c->g.nvox + 64)) return r;
-    HIP_TRY(c, launch_distance_field(offsets_of(c), c->g, c->dist, s));
+    HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    HIP_TRY(c, launch_distance_field(offsets_of(c), c->g, c->dist, c->aux_stream));
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+    c->dist_in_flight = true;
+    return HVRT_OK;
+}
+int join_distance_field(hvrt_ctx* c, hipStream_t s) {
+    if (!c->dist_in_flight) return HVRT_OK;
+    c->dist_in_flight = false;
+    HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    return HVRT_OK;
+}
+
+int make_ref_records_inner(hvrt_ctx* c, hipStream_t s, bool validate) {
+    c->ref_rec_valid = false;
+    if (!c->dist_in_flight) if (int r = fork_distance_field(c, s)) return r;
     // face bits: one bit per entry and face, padded by two words so that a 32-entry window read at the
     // last entry stays inside the array
     c->face_words = (c->n_refs + 63) / 64 * 2 + 2;
@@ -206,6 +227,13 @@ int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate) {
                          (unsigned long long)bad, c->n_tris);
     c->ref_rec_valid = true;
     return HVRT_OK;
+}
+
+// Builds the derived acceleration data; always rejoins the distance-field stream, whatever the outcome.
+int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate) {
+    const int r = make_ref_records_inner(c, s, validate);
+    const int j = join_distance_field(c, s);
+    return r ? r : j;
 }
 
 float ms_between(hipEvent_t a, hipEvent_t b) {
@@ -241,6 +269,9 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     c->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
+    if ((e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&c->stats, 8 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
@@ -263,6 +294,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
@@ -271,6 +303,9 @@ void hvrt_destroy(hvrt_ctx* c) {
     for (auto& ev : c->cam_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->cam_host) (void)hipHostFree(c->cam_host);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     delete c;
 }
 
@@ -312,6 +347,7 @@ static int adopt_mesh(hvrt_ctx* c, const void* src, uint32_t n_tris, hipMemcpyKi
     c->n_tris = n_tris;
     c->has_grid = false;
     c->cost_valid = false;
+    (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
     if (n_tris) {
         HIP_TRY(c, hipMemcpyAsync(c->tri_aos, src, (size_t)n_tris * 48, kind, c->stream));
         HIP_TRY(c, launch_prepare_records(c->tri_aos, c->tri_rec, n_tris, c->stream));
@@ -382,6 +418,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     if (!c->tri_aos && c->n_tris) return fail(c, HVRT_ERR_INVALID, "build_grid: no mesh");
     c->has_grid = false;
     c->cost_valid = false;
+    (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
     set_grid_params(c, nx, ny, nz, mn, mx, vs);
     const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox), n_chunks = npad / SCAN_CHUNK;
 
@@ -414,6 +451,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, s));
     HIP_TRY(c, hipEventRecord(c->ev[4], s));
+    if (int r = fork_distance_field(c, s)) return r;     // offsets are final from here on
     HIP_TRY(c, launch_sort(offsets_of(c), unsorted, vox_of, total, c->indices, c->long_queue, c->long_queue_capacity, c->stats, s));
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
     c->n_refs = total;
@@ -445,6 +483,7 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
     if (n_refs > 0xFFFFFFFFull) return fail(c, HVRT_ERR_OVERFLOW, "set_grid_csr: too many references");
     c->has_grid = false;
     c->cost_valid = false;
+    (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
     set_grid_params(c, nx, ny, nz, mn, mx, vs);
     const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox);
     if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
