@@ -292,7 +292,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         uint32_t pulled = 0;
         if (lane == 0) {
             pulled = atomicAdd(ra.tile_counter, 1u);
-            if (ra.order && pulled < n_tiles) pulled = ra.order[pulled];
+            if (pulled < n_tiles) {
+                if (ra.order) {
+                    pulled = ra.order[pulled];
+                } else {
+                    // no history for this shape yet: rows of tiles from the middle of the frame outwards.  The
+                    // reference's cameras look at the centre of the grid (TraceImages.cpp:125-197), so the
+                    // silhouette -- where the long tiles are -- surrounds the image centre and starts early.
+                    const uint32_t fi = pulled / tiles_frame, tf = pulled - fi * tiles_frame;
+                    const uint32_t q = tf / tiles_x, tx = tf - q * tiles_x;
+                    const uint32_t mid = tiles_y / 2, h = (q + 1) / 2;
+                    const uint32_t ty = (q & 1u) ? (mid >= h ? mid - h : tiles_y - 1 - (h - mid - 1))
+                                                 : (mid + h < tiles_y ? mid + h : (tiles_y - 1 - mid) + mid - h);
+                    pulled = fi * tiles_frame + ty * tiles_x + tx;
+                }
+            }
         }
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)pulled, 0);   // wave-uniform (an SGPR)
         if (tile >= n_tiles) break;
