@@ -215,3 +215,93 @@ def test_one_rank_rccl_group_collectives_and_renderer(ctx):
         assert np.array_equal(last.cpu().numpy().view(np.uint32), want.view(np.uint32))
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, out_dir):
+    """One of two real processes sharing the one GPU.  RCCL cannot put two ranks on one device, so the wire is
+    gloo with the tensors staged through host memory; everything else -- replicate_scene on a rank that does
+    NOT hold the mesh, the batch pipeline, the reassembly -- is the code bench.py runs at N > 1."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    real_broadcast, real_a2a = dist.broadcast, dist.all_to_all_single
+
+    class Done:
+        def wait(self):
+            return True
+
+    def staged_broadcast(t, src=0, group=None, async_op=False):
+        if t.is_cuda:
+            torch.cuda.synchronize()
+            h = t.cpu()
+            real_broadcast(h, src=src, group=group)
+            t.copy_(h)
+            torch.cuda.synchronize()
+        else:
+            real_broadcast(t, src=src, group=group)
+
+    def staged_a2a(out, inp, group=None, async_op=False):
+        torch.cuda.synchronize()           # the caller ordered the collective after the render on `cur`
+        hi, ho = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        real_a2a(ho, hi, group=group)
+        out.copy_(ho)
+        torch.cuda.synchronize()
+        return Done()
+
+    D.dist.broadcast = staged_broadcast
+    D.dist.all_to_all_single = staged_a2a
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        ctx = ra.Context(0)
+        dr = D.DistributedRenderer(ctx, rank, world, dev, tile_rows=16)
+        tris = meshgen.cube_sphere(20) if rank == 0 else None
+        mn, mx, vs3 = dr.replicate_scene(tris, (32, 32, 32))
+        info = ctx.grid_info()
+        off, idx = ctx.get_csr()
+        chk = torch.tensor([int(off.astype(np.int64).sum()), int(idx.astype(np.int64).sum()), int(info.n_refs)])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, dist.ReduceOp.MIN)
+        dist.all_reduce(hi, dist.ReduceOp.MAX)
+        assert torch.equal(lo, hi) and int(info.n_refs) > 0, "scene differs between ranks"
+        W, H = 203, 150
+        views = ["front", "side", "top"]
+        cams = [capi.make_camera_frame(*capi.default_camera(mn, mx, v)) for v in views]
+        dr.alloc_batch(W, H)
+        batches = [[(k + f) % 3 for f in range(world)] for k in range(3)]
+        got = []
+        for k in range(3):
+            done = dr.render_batch([cams[v] for v in batches[k]])
+            if done is not None:
+                torch.cuda.synchronize()
+                got.append(done.cpu().numpy().copy())
+        done = dr.flush()
+        torch.cuda.synchronize()
+        got.append(done.cpu().numpy().copy())
+        ok = len(got) == 3
+        for k in range(3):
+            want = ctx.render(cams[batches[k][rank]], W, H)[0]        # this rank owns frame index `rank`
+            ok = ok and np.array_equal(got[k].view(np.uint32), want.view(np.uint32))
+        flag = torch.tensor([int(ok)])
+        dist.all_reduce(flag, dist.ReduceOp.MIN)
+        if rank == 0:
+            np.save(os.path.join(out_dir, "ok.npy"), flag.numpy())
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_share_the_gpu_over_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "ok.npy")[0] == 1
