@@ -84,6 +84,11 @@ struct hvrt_ctx {
     void* out_buf[3] = {};  uint64_t out_cap[3] = {};   // rgb / hit / t staging for host-facing render
     void* io_buf[3] = {};   uint64_t io_cap[3] = {};    // trace staging: origins / dirs / hits
 
+    // large downloads go through two pinned bounce buffers (pageable-memory copies run at a fraction of the link)
+    static constexpr size_t PIN_CHUNK = 8u << 20;
+    char* pin_buf[2] = {};
+    hipEvent_t pin_ev[2] = {};
+
     hvrt_timings tm = {};
     bool render_pending = false;   // ev[6..7] recorded by an asynchronous render, not yet read
 };
@@ -130,6 +135,34 @@ int ensure_bytes(hvrt_ctx* c, void*& p, uint64_t& cap, uint64_t need) {
 
 int bind(hvrt_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
+    return HVRT_OK;
+}
+
+// Device -> caller's (pageable) host memory on stream s.  Small copies are issued directly and complete at the
+// caller's next stream synchronisation; large ones are pipelined through two pinned 8-MiB buffers -- the DMA of
+// chunk k overlaps the host memcpy of chunk k-1 -- and have completed on return.
+int download(hvrt_ctx* c, void* dst, const void* src, uint64_t bytes, hipStream_t s) {
+    if (bytes == 0) return HVRT_OK;
+    if (bytes < 4 * hvrt_ctx::PIN_CHUNK) {
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        return HVRT_OK;
+    }
+    for (int k = 0; k < 2; ++k) {
+        if (!c->pin_buf[k]) HIP_TRY(c, hipHostMalloc((void**)&c->pin_buf[k], hvrt_ctx::PIN_CHUNK, hipHostMallocDefault));
+        if (!c->pin_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
+    }
+    const uint64_t n = (bytes + hvrt_ctx::PIN_CHUNK - 1) / hvrt_ctx::PIN_CHUNK;
+    auto size_of = [&](uint64_t k) { return k + 1 < n ? (uint64_t)hvrt_ctx::PIN_CHUNK : bytes - k * hvrt_ctx::PIN_CHUNK; };
+    for (uint64_t k = 0; k <= n; ++k) {
+        if (k < n) {
+            HIP_TRY(c, hipMemcpyAsync(c->pin_buf[k & 1], (const char*)src + k * hvrt_ctx::PIN_CHUNK, size_of(k), hipMemcpyDeviceToHost, s));
+            HIP_TRY(c, hipEventRecord(c->pin_ev[k & 1], s));
+        }
+        if (k >= 1) {
+            HIP_TRY(c, hipEventSynchronize(c->pin_ev[(k - 1) & 1]));
+            memcpy((char*)dst + (k - 1) * hvrt_ctx::PIN_CHUNK, c->pin_buf[(k - 1) & 1], size_of(k - 1));
+        }
+    }
     return HVRT_OK;
 }
 
@@ -302,6 +335,8 @@ void hvrt_destroy(hvrt_ctx* c) {
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->cam_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->cam_host) (void)hipHostFree(c->cam_host);
+    for (auto& b : c->pin_buf) if (b) (void)hipHostFree(b);
+    for (auto& ev : c->pin_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -538,8 +573,8 @@ int hvrt_get_csr(hvrt_ctx* c, uint32_t* offsets, uint32_t* indices) {
     if (!c) return HVRT_ERR_INVALID;
     if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "get_csr: no grid");
     if (int r = bind(c)) return r;
-    if (offsets) HIP_TRY(c, hipMemcpyAsync(offsets, offsets_of(c), (c->g.nvox + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-    if (indices && c->n_refs) HIP_TRY(c, hipMemcpyAsync(indices, c->indices, c->n_refs * 4, hipMemcpyDeviceToHost, c->stream));
+    if (offsets) if (int r = download(c, offsets, offsets_of(c), (c->g.nvox + 1) * 4, c->stream)) return r;
+    if (indices && c->n_refs) if (int r = download(c, indices, c->indices, c->n_refs * 4, c->stream)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HVRT_OK;
 }
@@ -549,7 +584,7 @@ int hvrt_get_distance_field(hvrt_ctx* c, uint8_t* dist) {
     if (int r = bind(c)) return r;
     if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "get_distance_field: no grid");
     if (!dist) return fail(c, HVRT_ERR_INVALID, "get_distance_field: null output");
-    HIP_TRY(c, hipMemcpyAsync(dist, c->dist, c->g.nvox, hipMemcpyDeviceToHost, c->stream));
+    if (int r = download(c, dist, c->dist, c->g.nvox, c->stream)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HVRT_OK;
 }
@@ -708,9 +743,9 @@ int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int heig
     if (int r = hvrt_render_part_device(c, frame, width, height, spp, seed, height, 0, 1,
                                         rgb ? c->out_buf[0] : nullptr, hit_id ? c->out_buf[1] : nullptr,
                                         t ? c->out_buf[2] : nullptr, counters ? c->counters : nullptr)) return r;
-    if (rgb) HIP_TRY(c, hipMemcpyAsync(rgb, c->out_buf[0], npx * 12, hipMemcpyDeviceToHost, s));
-    if (hit_id) HIP_TRY(c, hipMemcpyAsync(hit_id, c->out_buf[1], npx * 4, hipMemcpyDeviceToHost, s));
-    if (t) HIP_TRY(c, hipMemcpyAsync(t, c->out_buf[2], npx * 4, hipMemcpyDeviceToHost, s));
+    if (rgb) if (int r = download(c, rgb, c->out_buf[0], npx * 12, s)) return r;
+    if (hit_id) if (int r = download(c, hit_id, c->out_buf[1], npx * 4, s)) return r;
+    if (t) if (int r = download(c, t, c->out_buf[2], npx * 4, s)) return r;
     if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     c->tm.render_ms = ms_between(c->ev[6], c->ev[7]);
@@ -747,8 +782,8 @@ int hvrt_render_views_rgb8(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_f
                                               counters ? c->counters : nullptr)) return r;
     uint8_t* d8 = (uint8_t*)c->out_buf[0] + f_bytes;
     HIP_TRY(c, launch_quantise_rgb8((const float*)c->out_buf[0], npx * 3, d8, s));
-    HIP_TRY(c, hipMemcpyAsync(rgb8, d8, npx * 3, hipMemcpyDeviceToHost, s));
-    if (hit_id) HIP_TRY(c, hipMemcpyAsync(hit_id, c->out_buf[1], npx * 4, hipMemcpyDeviceToHost, s));
+    if (int r = download(c, rgb8, d8, npx * 3, s)) return r;
+    if (hit_id) if (int r = download(c, hit_id, c->out_buf[1], npx * 4, s)) return r;
     if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     c->tm.render_ms = ms_between(c->ev[6], c->ev[7]);
@@ -787,7 +822,7 @@ int hvrt_trace(hvrt_ctx* c, const float* origins, const float* dirs, uint32_t n,
         HIP_TRY(c, launch_trace(scene_of(c), (const float*)c->io_buf[0], (const float*)c->io_buf[1], n,
                                 (hvrt_hit*)c->io_buf[2], counters ? c->counters : nullptr, s));
         HIP_TRY(c, hipEventRecord(c->ev[7], s));
-        HIP_TRY(c, hipMemcpyAsync(out, c->io_buf[2], (size_t)n * sizeof(hvrt_hit), hipMemcpyDeviceToHost, s));
+        if (int r = download(c, out, c->io_buf[2], (uint64_t)n * sizeof(hvrt_hit), s)) return r;
     }
     if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
