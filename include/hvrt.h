@@ -102,6 +102,16 @@ void* hvrt_stream(hvrt_ctx* ctx);
  * stream.  The stream must belong to the context's device and outlive its use here. */
 int hvrt_set_stream(hvrt_ctx* ctx, void* hip_stream);
 int hvrt_synchronize(hvrt_ctx* ctx);
+/* Traversal mode of all later hvrt_render* / hvrt_trace* calls.
+ *   0 (default)  the reference's traversal, quirks included (OctreeLikeRayTracer.cpp:155-336): start in the clamped
+ *                voxel of the origin, first voxel with any hit, last list entry that hits.
+ *   1            nearest-hit mode: enter the grid through the reference's rayBoxIntersection (GeometryUtils.cpp:15-37,
+ *                which its own traversal never calls), keep the nearest hit over the visited voxels, stop once it lies
+ *                before the current voxel's exit.  An extension for callers who want a right
+ *                image rather than the reference's; nothing in the reference pins it -- it is checked against the
+ *                CPU restatement and against brute force over all triangles.  Shading, outputs and counters keep
+ *                their meaning (a ray that misses the grid visits no voxel). */
+int hvrt_set_mode(hvrt_ctx* ctx, int mode);
 int hvrt_get_timings(const hvrt_ctx* ctx, hvrt_timings* out);
 
 /* ---- mesh ---------------------------------------------------------------------------------- */

@@ -186,6 +186,21 @@ int orc_ray_triangle(const float* tri, const float dir[3], const float org[3], f
 
 /* ---------------------------------------------------------------- traversal */
 
+/* rayBoxIntersection, GeometryUtils.cpp:15-37: reciprocal directions, products, nested std::max / std::min
+ * (a NaN or an empty slab falls out through the final compares). */
+int orc_ray_box(const float org[3], const float dir[3], const float bmin[3], const float bmax[3],
+                float* t_near, float* t_far) {
+    float inv[3], t1[3], t2[3];
+    for (int k = 0; k < 3; ++k) {
+        inv[k] = 1.0f / dir[k];
+        t1[k] = (bmin[k] - org[k]) * inv[k];
+        t2[k] = (bmax[k] - org[k]) * inv[k];
+    }
+    *t_near = max2(max2(min2(t1[0], t2[0]), min2(t1[1], t2[1])), min2(t1[2], t2[2]));
+    *t_far = min2(min2(max2(t1[0], t2[0]), max2(t1[1], t2[1])), max2(t1[2], t2[2]));
+    return *t_far >= *t_near && *t_far >= 0.0f;
+}
+
 void orc_trace(const orc_scene* s, const float org[3], const float dir[3],
                orc_hit* out, uint64_t counters[2]) {
     const int n[3] = { s->nx, s->ny, s->nz };
@@ -199,9 +214,18 @@ void orc_trace(const orc_scene* s, const float org[3], const float dir[3],
     out->hit = 0;
     out->t = FLT_MAX;
 
+    float start[3] = { org[0], org[1], org[2] };
+    if (s->mode == 1) {
+        /* nearest-hit mode: the traversal starts where the ray enters the grid (or at the origin inside it) */
+        const float bmin[3] = { s->min.x, s->min.y, s->min.z }, bmax[3] = { s->max.x, s->max.y, s->max.z };
+        float tn, tf;
+        if (!orc_ray_box(org, dir, bmin, bmax, &tn, &tf)) return;
+        const float t0 = max2(tn, 0.0f);
+        for (int k = 0; k < 3; ++k) { const float m = dir[k] * t0; start[k] = org[k] + m; }
+    }
     /* initializeTraversal, :155-195 (start voxel is the CLAMPED voxel of the origin). */
     for (int k = 0; k < 3; ++k) {
-        i[k] = clampi(f2i((org[k] - mn[k]) / vs[k]), 0, n[k] - 1);      /* :132-135 */
+        i[k] = clampi(f2i((start[k] - mn[k]) / vs[k]), 0, n[k] - 1);    /* :132-135 */
         step[k] = (dir[k] > 0) ? 1 : -1;                                 /* :170-172 */
         t_delta[k] = fabsf(vs[k] / dir[k]);                              /* :175-177 */
         int b = (dir[k] > 0) ? (i[k] + 1) : i[k];                        /* :181 */
@@ -227,7 +251,7 @@ void orc_trace(const orc_scene* s, const float org[3], const float dir[3],
             orc_vec3 v0 = { tr[0], tr[1], tr[2] }, v1 = { tr[3], tr[4], tr[5] }, v2 = { tr[6], tr[7], tr[8] };
             float t;
             ++nt;
-            if (ray_tri(v0, v1, v2, d, o, &t)) {
+            if (ray_tri(v0, v1, v2, d, o, &t) && (s->mode == 0 || t < out->t)) {
                 out->hit = 1; out->t = t;
                 out->normal[0] = tr[9]; out->normal[1] = tr[10]; out->normal[2] = tr[11];
                 out->point[0] = tr[0]; out->point[1] = tr[1]; out->point[2] = tr[2];  /* = v0, :286 */
@@ -236,7 +260,15 @@ void orc_trace(const orc_scene* s, const float org[3], const float dir[3],
                 found = 1;
             }
         }
-        if (found) break;                                                /* :326-329 */
+        if (s->mode == 0) {
+            if (found) break;                                            /* :326-329 */
+        } else {
+            /* the exit of this voxel is the smallest tMax as advanceToNextVoxel picks it; a hit at or before it
+             * cannot be beaten by anything in a later voxel (whose list would also be in a visited voxel's) */
+            const float t_next = (t_max[0] < t_max[1]) ? ((t_max[0] < t_max[2]) ? t_max[0] : t_max[2])
+                                                       : ((t_max[1] < t_max[2]) ? t_max[1] : t_max[2]);
+            if (out->hit && out->t <= t_next) break;
+        }
         /* advanceToNextVoxel, :201-260: literal nested strict '<'; ties and NaNs fall to else. */
         if (t_max[0] < t_max[1]) {
             if (t_max[0] < t_max[2]) { i[0] += step[0]; t_max[0] += t_delta[0]; }

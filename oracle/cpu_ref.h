@@ -48,6 +48,11 @@ typedef struct {
     uint32_t n_tris;
     const uint32_t* offsets; /* nx*ny*nz + 1, exclusive scan, flat index ix + nx*(iy + ny*iz) */
     const uint32_t* indices; /* offsets[nvox] entries, ascending per voxel */
+    orc_vec3 max;          /* VoxelGrid::maxBound (used by mode 1 only) */
+    int mode;              /* 0: the reference's traversal.  1: nearest-hit mode (an extension,
+                              nothing in the reference pins it): enter the grid through rayBoxIntersection
+                              (GeometryUtils.cpp:15-37), keep the nearest hit over all visited voxels, stop once
+                              it lies before the current voxel's exit. */
 } orc_scene;
 
 /* Mirrors cg_datastructures::RayHit (RayTracerCommon.h:17-29), 52 bytes. */
@@ -60,6 +65,10 @@ typedef struct {
     uint32_t triangle_index;
     uint32_t voxel_index;
 } orc_hit;
+
+/* GeometryUtils.cpp:15-37 (rayBoxIntersection, unused by the reference's own traversal). */
+int orc_ray_box(const float org[3], const float dir[3], const float bmin[3], const float bmax[3],
+                float* t_near, float* t_far);
 
 /* SceneCreator.cpp:49-84 (computeMeshBounds) over n points (xyz triples), in order. */
 void orc_mesh_bounds(const float* pts, uint64_t n, float mn[3], float mx[3]);

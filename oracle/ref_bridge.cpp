@@ -50,6 +50,20 @@ void ref_ray_triangle_batch(const float* tris, const float* dirs, const float* o
     for (unsigned i = 0; i < n; ++i) hit[i] = ref_ray_triangle(tris + 12ull * i, dirs + 3ull * i, orgs + 3ull * i, t + i);
 }
 
+// GeometryUtils::rayBoxIntersection (GeometryUtils.cpp:15-37); n rays against one box
+void ref_ray_box_batch(const float* orgs, const float* dirs, const float* bmin, const float* bmax, unsigned n,
+                       int* hit, float* t_near, float* t_far) {
+    const Vec3 lo = { bmin[0], bmin[1], bmin[2] }, hi = { bmax[0], bmax[1], bmax[2] };
+    for (unsigned i = 0; i < n; ++i) {
+        const Vec3 o = { orgs[3 * i], orgs[3 * i + 1], orgs[3 * i + 2] }, d = { dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2] };
+        const Ray r(o, d);
+        float tn = 0.0f, tf = 0.0f;
+        hit[i] = GeometryUtils::rayBoxIntersection(r, lo, hi, tn, tf) ? 1 : 0;
+        t_near[i] = tn;
+        t_far[i] = tf;
+    }
+}
+
 // GeometryUtils::computeTriangleMinMax (GeometryUtils.cpp:43-51)
 void ref_triangle_min_max(const float* tri12, float* mn, float* mx) {
     Triangle tr = make_tri(tri12);

@@ -20,7 +20,7 @@ HVRT_MISS = 0xFFFFFFFF
 
 # every symbol include/hvrt.h declares (tests check the library exports each of them)
 SYMBOLS = [
-    "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_set_stream", "hvrt_synchronize", "hvrt_get_timings",
+    "hvrt_create", "hvrt_destroy", "hvrt_last_error", "hvrt_stream", "hvrt_set_stream", "hvrt_synchronize", "hvrt_set_mode", "hvrt_get_timings",
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
@@ -279,6 +279,10 @@ class Context:
         t = Timings()
         self._ck(self._lib.hvrt_get_timings(self._h, C.byref(t)))
         return t
+
+    def set_mode(self, mode: int):
+        """0 = the reference's traversal (default), 1 = nearest-hit mode."""
+        self._ck(self._lib.hvrt_set_mode(self._h, mode))
 
     def synchronize(self):
         self._ck(self._lib.hvrt_synchronize(self._h))

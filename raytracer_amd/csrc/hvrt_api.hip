@@ -89,6 +89,8 @@ struct hvrt_ctx {
     char* pin_buf[2] = {};
     hipEvent_t pin_ev[2] = {};
 
+    int mode = 0;   // hvrt_set_mode
+
     hvrt_timings tm = {};
     bool render_pending = false;   // ev[6..7] recorded by an asynchronous render, not yet read
 };
@@ -186,6 +188,7 @@ void set_grid_params(hvrt_ctx* c, int nx, int ny, int nz, const float* mn, const
     c->g.vsx = vs[0]; c->g.vsy = vs[1]; c->g.vsz = vs[2];
     c->g.nvox = (uint64_t)nx * ny * nz;
     memcpy(c->max_bound, mx, 12);
+    c->g.bxx = mx[0]; c->g.bxy = mx[1]; c->g.bxz = mx[2];
 }
 
 SceneDev scene_of(const hvrt_ctx* c) {
@@ -361,6 +364,14 @@ int hvrt_synchronize(hvrt_ctx* c) {
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->render_pending) { c->tm.render_ms = ms_between(c->ev[6], c->ev[7]); c->render_pending = false; }
+    return HVRT_OK;
+}
+
+int hvrt_set_mode(hvrt_ctx* c, int mode) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (mode != 0 && mode != 1) return fail(c, HVRT_ERR_INVALID, "set_mode: mode %d is neither 0 (reference) nor 1 (nearest hit)", mode);
+    if (mode != c->mode) c->cost_valid = false;     // tile durations of the other mode say nothing about this one
+    c->mode = mode;
     return HVRT_OK;
 }
 
@@ -698,6 +709,7 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     RenderArgs ra;
     ra.frames = ds; ra.n_frames = n_frames;
     ra.width = width; ra.height = height; ra.spp = spp; ra.seed = seed;
+    ra.nearest = c->mode;
     ra.tile_rows = tile_rows; ra.part = part; ra.n_parts = n_parts;
     ra.local_rows = local_rows; ra.slab_rows = slab_rows;
     ra.rgb = (float*)d_rgb; ra.hit_id = (uint32_t*)d_hit_id; ra.t = (float*)d_t;
@@ -820,7 +832,7 @@ int hvrt_trace(hvrt_ctx* c, const float* origins, const float* dirs, uint32_t n,
         HIP_TRY(c, hipMemcpyAsync(c->io_buf[1], dirs, (size_t)n * 12, hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipEventRecord(c->ev[6], s));
         HIP_TRY(c, launch_trace(scene_of(c), (const float*)c->io_buf[0], (const float*)c->io_buf[1], n,
-                                (hvrt_hit*)c->io_buf[2], counters ? c->counters : nullptr, s));
+                                (hvrt_hit*)c->io_buf[2], counters ? c->counters : nullptr, c->mode, s));
         HIP_TRY(c, hipEventRecord(c->ev[7], s));
         if (int r = download(c, out, c->io_buf[2], (uint64_t)n * sizeof(hvrt_hit), s)) return r;
     }
@@ -839,7 +851,7 @@ int hvrt_trace_device(hvrt_ctx* c, const void* d_origins, const void* d_dirs, ui
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     HIP_TRY(c, launch_trace(scene_of(c), (const float*)d_origins, (const float*)d_dirs, n, (hvrt_hit*)d_hits,
-                            (unsigned long long*)d_counters, s));
+                            (unsigned long long*)d_counters, c->mode, s));
     HIP_TRY(c, hipEventRecord(c->ev[7], s));
     c->render_pending = true;      // hvrt_synchronize reads the pair of events into render_ms
     return HVRT_OK;

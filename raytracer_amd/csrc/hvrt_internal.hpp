@@ -15,6 +15,7 @@ struct GridParams {
     float mnx, mny, mnz;   // VoxelGrid::minBound
     float vsx, vsy, vsz;   // VoxelGrid::voxelSize (uniform when built by us)
     uint64_t nvox;
+    float bxx, bxy, bxz;   // VoxelGrid::maxBound (only the nearest-hit mode's entry test reads it)
 };
 
 // HBM layout of the scene (all owned by the context):
@@ -51,6 +52,7 @@ struct RenderArgs {
     int width, height;       // full frame
     int spp;
     uint32_t seed;
+    int nearest;             // 0: the reference's traversal; 1: nearest-hit mode (hvrt_set_mode)
     int tile_rows, part, n_parts;
     int local_rows;          // rows owned by this part
     int slab_rows;           // rows between consecutive frames' outputs (>= local_rows)
@@ -103,7 +105,7 @@ uint64_t render_tile_count(int width, int local_rows, int n_frames);
 hipError_t launch_order_build(const uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum,
                               uint32_t* block_count, uint32_t* order, hipStream_t s);
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n,
-                        hvrt_hit* out, unsigned long long* counters, hipStream_t s);
+                        hvrt_hit* out, unsigned long long* counters, int nearest, hipStream_t s);
 hipError_t launch_quantise_rgb8(const float* rgb /* 16-B aligned */, uint64_t n_values, uint8_t* out /* 4-B aligned */, hipStream_t s);
 hipError_t launch_assemble(const void* parts, int width, int height, int tile_rows, int n_parts,
                            int slab_rows, int bytes_per_pixel, void* frame, hipStream_t s);

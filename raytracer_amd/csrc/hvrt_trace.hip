@@ -21,6 +21,10 @@ __device__ __forceinline__ int f2i(float f) {
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// std::min / std::max as libstdc++ / MSVC define them (GeometryUtils.cpp:33-34 nests them).
+__device__ __forceinline__ float min2(float a, float b) { return b < a ? b : a; }
+__device__ __forceinline__ float max2(float a, float b) { return a < b ? b : a; }
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
 __device__ __forceinline__ V3 add(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
@@ -84,16 +88,35 @@ struct TraceResult {
 //   * the flat voxel index ix + nx*(iy + ny*iz) is updated incrementally (32-bit: Nvox < 2^32);
 //   * advanceToNextVoxel's nested strict '<' (:201-260) becomes three compares and selects with the same
 //     truth table (ties and NaNs fall to the else arms exactly as written there).
-template <bool COUNT, bool INLINE>
+//
+// NEAREST (hvrt_set_mode(1); an extension, SURVEY 8f row 4 -- the reference has no such mode): the ray enters
+// the grid through the reference's own rayBoxIntersection (GeometryUtils.cpp:15-37, unused by its traversal),
+// the nearest hit over all visited voxels is kept, and the walk stops once that hit lies at or before the
+// exit of the current voxel -- nothing in a later voxel can beat it, because a triangle hit before that exit
+// is listed in a voxel already visited.  The skip of entries tested one step ago stays valid (their result
+// is remembered in the running minimum).  Same kernels, same data.
+template <bool COUNT, bool INLINE, bool NEAREST>
 __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d) {
     const GridParams& g = sc.g;
     TraceResult r;
     r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
 
+    V3 st = o;
+    if (NEAREST) {
+        const float ivx = 1.0f / d.x, ivy = 1.0f / d.y, ivz = 1.0f / d.z;
+        const float tx1 = (g.mnx - o.x) * ivx, tx2 = (g.bxx - o.x) * ivx;
+        const float ty1 = (g.mny - o.y) * ivy, ty2 = (g.bxy - o.y) * ivy;
+        const float tz1 = (g.mnz - o.z) * ivz, tz2 = (g.bxz - o.z) * ivz;
+        const float tn = max2(max2(min2(tx1, tx2), min2(ty1, ty2)), min2(tz1, tz2));
+        const float tf = min2(min2(max2(tx1, tx2), max2(ty1, ty2)), max2(tz1, tz2));
+        if (!(tf >= tn && tf >= 0.0f)) return r;
+        const float t0 = max2(tn, 0.0f);
+        st = { o.x + d.x * t0, o.y + d.y * t0, o.z + d.z * t0 };
+    }
     // initializeTraversal, :155-195 (start voxel = CLAMPED voxel of the origin, no entry test)
-    const int ix = clampi(f2i((o.x - g.mnx) / g.vsx), 0, g.nx - 1);
-    const int iy = clampi(f2i((o.y - g.mny) / g.vsy), 0, g.ny - 1);
-    const int iz = clampi(f2i((o.z - g.mnz) / g.vsz), 0, g.nz - 1);
+    const int ix = clampi(f2i((st.x - g.mnx) / g.vsx), 0, g.nx - 1);
+    const int iy = clampi(f2i((st.y - g.mny) / g.vsy), 0, g.ny - 1);
+    const int iz = clampi(f2i((st.z - g.mnz) / g.vsz), 0, g.nz - 1);
     const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;   // stepX = (dir > 0) ? 1 : -1
     const float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
     float tmx = ((g.mnx + (float)(px ? ix + 1 : ix) * g.vsx) - o.x) / d.x;
@@ -134,6 +157,9 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
         f += last;                                                              \
         alive = (rx | ry | rz) >= 0;                                            \
     } while (0)
+    // nearest-hit mode: is the kept hit at or before the exit of the current voxel (the tMax the next step takes)?
+#define HVRT_NEAREST_DONE()                                                     \
+    (r.tri != HVRT_MISS && r.t <= (((tmx < tmy ? tmx : tmy) < tmz) ? (tmx < tmy ? tmx : tmy) : tmz))
 #define HVRT_LOAD_VOXEL()                                                       \
     do {                                                                        \
         const uint32_t* pv = offs + f;                                          \
@@ -150,6 +176,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
         // k = 1, a few in open space) -- because a vector load costs the L1 a slot per quad of lanes, however
         // few of them want it.
         bool search = alive;
+        bool done = false;
         for (;;) {
             uint32_t dd = 255u;
             if (search) dd = dist[f];
@@ -168,6 +195,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                 }
             }
             for (int i = 0; i < k; ++i) {
+                if (NEAREST && search && HVRT_NEAREST_DONE()) { done = true; search = false; }
                 if (search) {
                     HVRT_ADVANCE();
                     search = alive;
@@ -177,6 +205,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                 }
             }
         }
+        if (NEAREST && done) break;
         if (!alive) break;
         HVRT_LOAD_VOXEL();
         // a surviving x step implies nx > 1 (it would have left a 1-wide grid), so fsx, fsy, fsz are told
@@ -215,14 +244,16 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                         // 36 of the record's 48 bytes; the triangle id (10th dword) is fetched only on a hit
                         const float4 c0 = rec[0], c1 = rec[1];
                         const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
-                        if (ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, t)) {
+                        if (ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, t) &&
+                            (!NEAREST || t < r.t)) {
                             r.tri = __float_as_uint(reinterpret_cast<const float*>(rec + 2)[1]); r.t = t; found = true;
                         }
                     } else {
                         const uint32_t ti = sc.indices[j];
                         const float4 r0 = sc.tri_rec[3ull * ti], r1 = sc.tri_rec[3ull * ti + 1];
                         const float e2z = reinterpret_cast<const float*>(sc.tri_rec + 3ull * ti + 2)[0];
-                        if (ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, e2z }, o, d, t)) {
+                        if (ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, e2z }, o, d, t) &&
+                            (!NEAREST || t < r.t)) {
                             r.tri = ti; r.t = t; found = true;
                         }
                     }
@@ -232,7 +263,8 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
 #ifndef HVRT_DIAG
         if (COUNT) r.nt += b1 - b0;
 #endif
-        if (found) break;   // :326-329
+        if (NEAREST) { if (HVRT_NEAREST_DONE()) break; }
+        else if (found) break;   // :326-329
         HVRT_ADVANCE();
         if (!alive) break;
 #ifndef HVRT_DIAG
@@ -240,6 +272,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
 #endif
     }
 #undef HVRT_ADVANCE
+#undef HVRT_NEAREST_DONE
 #undef HVRT_LOAD_VOXEL
     return r;
 }
@@ -278,7 +311,7 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 
 // Persistent threads: every wave loops pulling 8x8 pixel tiles until the queue is empty; the
 // exit condition (tile >= n_tiles) is reached by every wave whatever the grid size.
-template <bool COUNT, bool INLINE>
+template <bool COUNT, bool INLINE, bool NEAREST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render(SceneDev sc, RenderArgs ra) {
     const int lane = threadIdx.x & 63;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const float v = ((float)y + jy) / (float)ra.height;
                 // generateRay, :361-364
                 const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
-                const TraceResult r = trace_ray<COUNT, INLINE>(sc, org, d);
+                const TraceResult r = trace_ray<COUNT, INLINE, NEAREST>(sc, org, d);
                 const V3 c = shade(sc, r, org, v);
                 if (ra.spp == 1) acc = c; else acc = add(acc, c);
                 if (s == 0) { hit0 = r.tri; t0 = r.t; }
@@ -421,7 +454,7 @@ __global__ __launch_bounds__(256) void k_order_place(const uint32_t* __restrict_
 }
 
 // traceRay batch: one lane per ray, RayHit records out (OctreeLikeRayTracer.cpp:124-126, :283-288).
-template <bool INLINE>
+template <bool INLINE, bool NEAREST>
 __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const float* __restrict__ origins,
                                                const float* __restrict__ dirs, uint32_t n,
                                                hvrt_hit* __restrict__ out, unsigned long long* counters) {
@@ -430,7 +463,7 @@ __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const float* __restr
     if (i < n) {
         const V3 o = { origins[3ull * i], origins[3ull * i + 1], origins[3ull * i + 2] };
         const V3 d = { dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2] };
-        const TraceResult r = trace_ray<true, INLINE>(sc, o, d);
+        const TraceResult r = trace_ray<true, INLINE, NEAREST>(sc, o, d);
         hvrt_hit h;
         h.hit = r.tri != HVRT_MISS;
         h.t = r.t;
@@ -505,8 +538,16 @@ hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hi
     const uint64_t cap = (uint64_t)n_cus * 8;   // 8 x 256-thread workgroups fill a CU's 32 wave slots
     if (blocks > cap) blocks = cap;
     const bool il = sc.ref_rec != nullptr;
-    if (ra.counters) { if (il) k_render<true, true><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); else k_render<true, false><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); }
-    else             { if (il) k_render<false, true><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); else k_render<false, false><<<(unsigned)blocks, 256, 0, s>>>(sc, ra); }
+    const unsigned nb = (unsigned)blocks;
+#define HVRT_LAUNCH(C, I, N) k_render<C, I, N><<<nb, 256, 0, s>>>(sc, ra)
+    if (ra.nearest) {
+        if (ra.counters) { if (il) HVRT_LAUNCH(true, true, true); else HVRT_LAUNCH(true, false, true); }
+        else             { if (il) HVRT_LAUNCH(false, true, true); else HVRT_LAUNCH(false, false, true); }
+    } else {
+        if (ra.counters) { if (il) HVRT_LAUNCH(true, true, false); else HVRT_LAUNCH(true, false, false); }
+        else             { if (il) HVRT_LAUNCH(false, true, false); else HVRT_LAUNCH(false, false, false); }
+    }
+#undef HVRT_LAUNCH
     return hipGetLastError();
 }
 
@@ -520,10 +561,16 @@ hipError_t launch_order_build(const uint32_t* tile_cost, uint32_t n_tiles, const
 }
 
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n, hvrt_hit* out,
-                        unsigned long long* counters, hipStream_t s) {
+                        unsigned long long* counters, int nearest, hipStream_t s) {
     if (n == 0) return hipSuccess;
-    if (sc.ref_rec) k_trace<true><<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
-    else k_trace<false><<<(n + 255) / 256, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+    const unsigned nb = (n + 255) / 256;
+    if (nearest) {
+        if (sc.ref_rec) k_trace<true, true><<<nb, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+        else k_trace<false, true><<<nb, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+    } else {
+        if (sc.ref_rec) k_trace<true, false><<<nb, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+        else k_trace<false, false><<<nb, 256, 0, s>>>(sc, origins, dirs, n, out, counters);
+    }
     return hipGetLastError();
 }
 

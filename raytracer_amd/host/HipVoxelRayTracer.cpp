@@ -167,6 +167,8 @@ std::vector<std::vector<unsigned char>> HipVoxelRayTracer::renderViewsRgb8(const
     return out;
 }
 
+void HipVoxelRayTracer::setNearestHit(bool on) { ck(scene_->handle(), hvrt_set_mode(scene_->handle(), on ? 1 : 0), "hvrt_set_mode"); }
+
 std::vector<RayHit> HipVoxelRayTracer::traceRays(const std::vector<Ray>& rays) {
     const size_t n = rays.size();
     std::vector<float> o(3 * n), d(3 * n);

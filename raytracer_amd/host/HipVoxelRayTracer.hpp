@@ -62,6 +62,10 @@ public:
     std::vector<std::vector<unsigned char>> renderViewsRgb8(const std::vector<cg_datastructures::Camera>& cameras,
                                                             int width, int height);
 
+    // false (default): the reference's traversal.  true: nearest-hit mode (hvrt_set_mode(1)), an extension for
+    // callers who want a right image rather than the reference's; see include/hvrt.h.
+    void setNearestHit(bool on);
+
     // Batched traceRay and the statistics the reference logs (OctreeLikeRayTracer.cpp:57-65).
     std::vector<cg_datastructures::RayHit> traceRays(const std::vector<cg_datastructures::Ray>& rays);
     unsigned long long voxelsTraversed() const { return voxels_; }

@@ -19,6 +19,9 @@ elif which == "small":
     tris, g, W, H = meshgen.cube_sphere(58), 50, 800, 600
 spp = 16 if which == "c4" else 1
 ctx = ra.Context(0)
+import os
+if os.environ.get("HVRT_TIME_MODE"):          # 1: nearest-hit mode (hvrt_set_mode)
+    ctx.set_mode(int(os.environ["HVRT_TIME_MODE"]))
 ctx.set_mesh(tris)
 mn, mx = ctx.mesh_bounds()
 vs = capi.voxel_size(mn, mx, g, g, g)

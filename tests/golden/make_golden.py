@@ -68,9 +68,49 @@ def mt_cases(rng, n_random=3000):
     return (np.asarray(tris, np.float32), np.asarray(dirs, np.float32), np.asarray(orgs, np.float32))
 
 
+def ray_box_vectors():
+    """rayBoxIntersection (GeometryUtils.cpp:15-37): random rays against a box, rays inside it, axis-parallel
+    rays (zero components: +-inf reciprocals, 0 * inf = NaN on a face), NaN / inf inputs."""
+    r = oracle.ref()
+    rng = np.random.default_rng(20261111)
+    n = 3000
+    bmin = np.array([-1.0, -0.5, 0.25], np.float32)
+    bmax = np.array([1.0, 1.5, 2.0], np.float32)
+    o = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    o[:300] = rng.uniform(bmin, bmax, (300, 3)).astype(np.float32)             # origins inside
+    aim = rng.random(n) < 0.5
+    tgt = rng.uniform(bmin - 0.2, bmax + 0.2, (n, 3))
+    dd = tgt - o
+    dd = (dd / np.maximum(np.linalg.norm(dd, axis=1, keepdims=True), 1e-9)).astype(np.float32)
+    d[aim] = dd[aim]
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0], [0.0, -0.0, 1.0],
+                     [np.nan, 0, 1], [0, np.inf, 0], [1, 1, 0], [0, 1, 1]], np.float32)
+    k = 300
+    for a in axes:
+        d[k:k + 40] = a
+        k += 40
+    o[k:k + 20] = bmin                                                         # on the min corner
+    o[k + 20:k + 40, 0] = bmin[0]                                              # on a face, sliding along it
+    d[k + 20:k + 40, 0] = 0.0
+    o[k + 40:k + 44] = [np.nan, 0, 0]
+    o[k + 44:k + 48] = [np.inf, 0, 0]
+    hit = np.zeros(n, np.int32)
+    tn = np.zeros(n, np.float32)
+    tf = np.zeros(n, np.float32)
+    r.ref_ray_box_batch(p(o), p(d), p(bmin), p(bmax), C.c_uint(n), p(hit), p(tn), p(tf))
+    np.savez_compressed(os.path.join(HERE, "raybox_vectors.npz"), orgs=o, dirs=d, bmin=bmin, bmax=bmax, hit=hit,
+                        t_near_bits=tn.view(np.uint32), t_far_bits=tf.view(np.uint32))
+    print("raybox_vectors", n, "cases,", int(hit.sum()), "hits")
+
+
 def main():
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libref.so missing: run `make -C oracle ref` where /root/reference exists")
+    if "--only-raybox" in sys.argv:       # added after the other files were committed; leaves them untouched
+        ray_box_vectors()
+        return
     r = oracle.ref()
     rng = np.random.default_rng(20261110)
 
@@ -138,6 +178,8 @@ def main():
         np.savez_compressed(os.path.join(HERE, f"stl_{kind}_expected.npz"), coords_bits=co.view(np.uint32), tris=ti,
                             normals_bits=nr.view(np.uint32))
         print("stl", kind, soup.shape[0], "written ->", ti.shape[0], "kept,", co.shape[0], "vertices")
+
+    ray_box_vectors()
 
 
 if __name__ == "__main__":

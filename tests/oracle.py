@@ -26,7 +26,8 @@ class Frame(C.Structure):
 
 class Scene(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int), ("min", V3), ("vs", V3),
-                ("tris", C.c_void_p), ("n_tris", C.c_uint32), ("offsets", C.c_void_p), ("indices", C.c_void_p)]
+                ("tris", C.c_void_p), ("n_tris", C.c_uint32), ("offsets", C.c_void_p), ("indices", C.c_void_p),
+                ("max", V3), ("mode", C.c_int)]
 
 
 HIT_DTYPE = np.dtype([("hit", "<u4"), ("t", "<f4"), ("point", "<f4", 3), ("origin", "<f4", 3),
@@ -49,6 +50,7 @@ def lib() -> C.CDLL:
         l.orc_voxel_size.restype = C.c_float
         l.orc_voxelize.restype = C.c_uint64
         l.orc_ray_triangle.restype = C.c_int
+        l.orc_ray_box.restype = C.c_int
         _lib = l
     return _lib
 
@@ -119,14 +121,21 @@ def frame_to_array(f) -> np.ndarray:
 class OracleScene:
     """Keeps the numpy arrays alive next to the C struct."""
 
-    def __init__(self, tri_aos, nx, ny, nz, mn, vs3, offsets, indices):
+    def __init__(self, tri_aos, nx, ny, nz, mn, vs3, offsets, indices, mx=None, mode=0):
         self.tris = np.ascontiguousarray(tri_aos, np.float32).reshape(-1, 12)
         self.offsets = np.ascontiguousarray(offsets, np.uint32)
         self.indices = np.ascontiguousarray(indices, np.uint32)
         vs3 = np.broadcast_to(np.asarray(vs3, np.float32), (3,))
         self.c = Scene(nx, ny, nz, V3(*[float(x) for x in mn]), V3(*[float(x) for x in vs3]),
                        self.tris.ctypes.data, self.tris.shape[0], self.offsets.ctypes.data,
-                       self.indices.ctypes.data if self.indices.size else None)
+                       self.indices.ctypes.data if self.indices.size else None,
+                       V3(*[float(x) for x in (mx if mx is not None else (0, 0, 0))]), mode)
+
+    def set_mode(self, mode: int, mx=None):
+        """0 = the reference's traversal; 1 = nearest-hit mode (needs the grid's maxBound)."""
+        if mx is not None:
+            self.c.max = V3(*[float(x) for x in mx])
+        self.c.mode = mode
 
     def render(self, frame, W, H, spp=1, seed=0, threads=8, rows=None):
         """Full-frame arrays; rows=(y0,y1) limits the work (other rows stay zero)."""

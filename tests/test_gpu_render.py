@@ -249,6 +249,57 @@ def test_views_rgb8_is_the_float_frames_quantised_like_the_reference(ctx):
     assert np.array_equal(got[:-1], _quantise_ref(vals)) and got[-1] == 0
 
 
+NEAREST_SCENES = {
+    "sphere_24": lambda: (meshgen.cube_sphere(16), (24, 24, 24)),
+    "coarse_grid_front_and_back_share_voxels": lambda: (meshgen.cube_sphere(16), (3, 3, 3)),
+    "skewed_long_lists": lambda: (meshgen.skewed_statue(12, 60), (16, 16, 16)),
+    "slivers": lambda: (meshgen.slivers(300, 7), (20, 20, 20)),
+    "offcentre_noncubic": lambda: (meshgen.cube_sphere(14, 0.7, center=(3.0, -2.0, 11.5)), (30, 11, 19)),
+}
+
+
+@pytest.mark.parametrize("name", sorted(NEAREST_SCENES))
+def test_nearest_hit_mode_matches_the_oracle(ctx, name):
+    """hvrt_set_mode(1) (extension, no reference counterpart -- parity unpinned by the reference; the oracle's
+    mode 1 is itself checked against brute force over all triangles in test_oracle_pinning.py): frames from
+    three cameras, a camera inside the mesh, and a ray batch, bit for bit incl. the counters; then back to
+    mode 0, which must be the reference's frame again."""
+    tris, dims = NEAREST_SCENES[name]()
+    sc, mn, mx = setup_scene(ctx, tris, dims)
+    front = capi.make_camera_frame(*capi.default_camera(mn, mx))
+    ref_frame = ctx.render(front, 160, 120)
+    try:
+        ctx.set_mode(1)
+        sc.set_mode(1, mx)
+        for view in ("front", "side", "top"):
+            fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view))
+            assert_frames_equal(ctx.render(fr, 160, 120), sc.render(fr, 160, 120, threads=4))
+            assert_frames_equal(ctx.render(fr, 160, 120), sc.render(fr, 160, 120, threads=4))   # re-ordered launch
+        c = (np.asarray(mn) + np.asarray(mx)) / 2
+        inside = capi.make_camera_frame(tuple(c), tuple(c + np.array([0.3, 0.2, 1.0], np.float32)), (0, 1, 0), 80.0, 4 / 3)
+        assert_frames_equal(ctx.render(inside, 120, 90, spp=2, seed=3), sc.render(inside, 120, 90, spp=2, seed=3, threads=4))
+        rng = np.random.default_rng(11)
+        n = 3000
+        o = (c + rng.uniform(-2.5, 2.5, (n, 3)) * (np.asarray(mx) - np.asarray(mn))).astype(np.float32)
+        tgt = c + rng.normal(size=(n, 3)) * 0.3 * (np.asarray(mx) - np.asarray(mn))
+        d = tgt - o
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        d[:12] = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0], [np.nan, 0, 1],
+                           [0, np.inf, 0], [1, 1, 0], [0.0, -0.0, 1.0], [0, 1, 1]], np.float32)
+        o[12:24] = np.asarray(mn, np.float32)                      # on the grid's min corner
+        got, gcnt = ctx.trace(o, d)
+        exp, ecnt = sc.trace(o, d)
+        assert got.tobytes() == exp.tobytes() and np.array_equal(gcnt, ecnt)
+        assert 0 < got["hit"].sum() < n
+    finally:
+        ctx.set_mode(0)
+        sc.set_mode(0)
+    assert_frames_equal(ctx.render(front, 160, 120), ref_frame)
+    assert_frames_equal(ref_frame, sc.render(front, 160, 120, threads=4))
+    with pytest.raises(capi.HvrtError):
+        ctx.set_mode(2)
+
+
 def test_render_requires_a_scene(ctx):
     ctx.set_mesh(meshgen.box())      # drops any grid
     fr = capi.make_camera_frame((0, 0, -5), (0, 0, 0), (0, 1, 0), 60.0, 4 / 3)

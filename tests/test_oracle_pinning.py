@@ -208,3 +208,55 @@ def test_survey_appendix_c_recorded_reference_outputs():
     assert h["triangle_index"] == 18099 and cc[0] == 5       # "5 voxels (spurious first X step)"
     h, cc = probe(410, 300)
     assert h["hit"] == 0 and cc[0] == 50                     # "MISS ..., 50 voxels (X never steps)"
+
+
+def test_ray_box_golden():
+    """rayBoxIntersection (GeometryUtils.cpp:15-37), the entry test of the nearest-hit mode: decision and both
+    distances bit for bit against the real function's outputs (zero / NaN / inf direction components included)."""
+    z = np.load(os.path.join(G, "raybox_vectors.npz"))
+    o, d, bmin, bmax = z["orgs"], z["dirs"], z["bmin"], z["bmax"]
+    l = oracle.lib()
+    tn, tf = np.zeros(1, np.float32), np.zeros(1, np.float32)
+    for i in range(o.shape[0]):
+        hit = l.orc_ray_box(C.c_void_p(o.ctypes.data + 12 * i), C.c_void_p(d.ctypes.data + 12 * i), _p(bmin), _p(bmax),
+                            _p(tn), _p(tf))
+        assert hit == z["hit"][i], i
+        assert tn.view(np.uint32)[0] == z["t_near_bits"][i] and tf.view(np.uint32)[0] == z["t_far_bits"][i], i
+
+
+def test_nearest_hit_mode_is_the_brute_force_nearest_hit():
+    """The oracle's mode 1 (extension; the reference has no such mode -- parity unpinned): for
+    every ray, the triangle and t it reports are those of the smallest t over ALL triangles of the mesh
+    (Moller-Trumbore as the reference computes it), on a closed mesh seen from outside and from inside."""
+    tris = meshgen.cube_sphere(12)
+    sc, mn, mx, vs = oracle.build_scene(tris, 20, 20, 20)
+    sc.set_mode(1, mx)
+    rng = np.random.default_rng(3)
+    n = 1500
+    o = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    o[:200] = rng.uniform(-0.5, 0.5, (200, 3))                   # inside the sphere
+    tgt = rng.normal(size=(n, 3)) * 0.6
+    d = tgt - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    got, _ = sc.trace(o, d)
+    T = tris.shape[0]
+    n_hit = 0
+    for i in range(n):
+        hit, t = orc_mt(tris, np.repeat(d[i:i + 1], T, 0), np.repeat(o[i:i + 1], T, 0))
+        if hit.any():
+            tt = np.where(hit == 1, t, np.float32(np.inf))
+            best = float(tt.min())
+            assert got["hit"][i] == 1 and got["t"][i] == np.float32(best), i
+            assert tt[got["triangle_index"][i]] == np.float32(best), i
+            n_hit += 1
+        else:
+            assert got["hit"][i] == 0, i
+    assert n_hit > n // 3
+    # on a grid so coarse that front and back faces share voxels the reference's rule ("first voxel with a hit,
+    # last entry that hits") is visibly not nearest-hit, while mode 1 still is
+    sc2, mn2, mx2, vs2 = oracle.build_scene(tris, 2, 2, 2)
+    ref0, _ = sc2.trace(o, d)
+    sc2.set_mode(1, mx2)
+    near, _ = sc2.trace(o, d)
+    assert (ref0["t"] != near["t"]).any()
+    assert np.array_equal(near["t"].view(np.uint32), got["t"].view(np.uint32))      # grid-independent
