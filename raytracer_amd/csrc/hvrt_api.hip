@@ -75,9 +75,16 @@ struct hvrt_ctx {
     uint32_t* tile_cost = nullptr;  uint64_t tile_cost_capacity = 0;
     uint32_t* tile_order = nullptr; uint64_t tile_order_capacity = 0;
     uint32_t* order_blocks = nullptr; uint64_t order_blocks_capacity = 0;
+    uint32_t* split_tiles = nullptr; uint64_t split_tiles_capacity = 0;
+    hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
+    // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
+    // Read without waiting -- a stale answer only delays the switch by a launch.  Starts at "some".
+    uint32_t* split_hint = nullptr;
+    uint32_t* split_hint_dev = nullptr;    // the same word as the device addresses it
     unsigned long long* cost_sum = nullptr;   // 2 x u64: this launch's and the previous launch's sum of tile costs
     int cost_parity = 0;
     bool adaptive_order = true;    // HVRT_TILE_ORDER=0 keeps the natural order
+    bool adaptive_split = true;    // HVRT_TILE_SPLIT=0 leaves every tile to k_render
     bool cost_valid = false;
     int cost_key[8] = {};
     unsigned long long* counters = nullptr;   // 2 x u64
@@ -308,6 +315,11 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_split_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_split_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipHostMalloc((void**)&c->split_hint, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    *c->split_hint = 1u;
+    if ((e = hipHostGetDevicePointer((void**)&c->split_hint_dev, c->split_hint, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipMalloc((void**)&c->stats, 8 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
@@ -318,6 +330,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     for (auto& ev : c->cam_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
     if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_i, 2048 * 6 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
@@ -332,18 +345,21 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
-                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order,
+                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->cam_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->cam_host) (void)hipHostFree(c->cam_host);
+    if (c->split_hint) (void)hipHostFree(c->split_hint);
     for (auto& b : c->pin_buf) if (b) (void)hipHostFree(b);
     for (auto& ev : c->pin_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_split_fork) (void)hipEventDestroy(c->ev_split_fork);
+    if (c->ev_split_join) (void)hipEventDestroy(c->ev_split_join);
     delete c;
 }
 
@@ -701,9 +717,11 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     // tile order: longest first, from the previous launch of the same shape
     const int key[8] = { width, height, tile_rows, part, n_parts, n_frames, spp, 1 };
     const bool grew = c->tile_cost_capacity < n_tiles || c->tile_order_capacity < n_tiles;
+    const uint64_t order_blocks = (n_tiles + 255) / 256;
     if (int r = ensure<uint32_t>(c, c->tile_cost, c->tile_cost_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->tile_order, c->tile_order_capacity, n_tiles)) return r;
-    if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, (n_tiles + 255) / 256 + 1)) return r;
+    if (int r = ensure<uint32_t>(c, c->split_tiles, c->split_tiles_capacity, n_tiles)) return r;
+    if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, 2 * (order_blocks + 1))) return r;
     const bool reuse = c->adaptive_order && c->cost_valid && !grew && memcmp(key, c->cost_key, sizeof key) == 0;
 
     RenderArgs ra;
@@ -716,6 +734,8 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     ra.counters = (unsigned long long*)d_counters;
     ra.tile_counter = c->tile_counter;
     ra.order = reuse ? c->tile_order : nullptr;
+    ra.split_tiles = c->split_tiles;
+    ra.n_split = c->order_blocks + order_blocks;
     ra.tile_cost = c->tile_cost;
     unsigned long long* prev_sum = c->cost_sum + c->cost_parity;
     c->cost_parity ^= 1;
@@ -723,9 +743,22 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
-    if (reuse && n_tiles)
-        HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, prev_sum, c->order_blocks, c->tile_order, s));
-    HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, s));
+    if (reuse && n_tiles) {
+        const bool may_split = c->adaptive_split && *(volatile uint32_t*)c->split_hint != 0u;
+        HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, prev_sum, c->n_cus, may_split, c->order_blocks,
+                                      c->tile_order, c->split_tiles, c->split_hint_dev, s));
+        if (may_split) {
+            // the tiles too long for one wave go first and beside the others, on the second stream
+            HIP_TRY(c, hipEventRecord(c->ev_split_fork, s));
+            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_split_fork, 0));
+            HIP_TRY(c, launch_render_split(scene_of(c), ra, c->n_cus, c->aux_stream));
+            HIP_TRY(c, hipEventRecord(c->ev_split_join, c->aux_stream));
+        }
+        HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, s));
+        if (may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
+    } else {
+        HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, s));
+    }
     HIP_TRY(c, hipEventRecord(c->ev[7], s));
     memcpy(c->cost_key, key, sizeof key);
     c->cost_valid = true;

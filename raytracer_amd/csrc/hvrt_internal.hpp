@@ -66,6 +66,10 @@ struct RenderArgs {
     // tile_cost; the next launch of the same shape starts with the long tiles of this one (k_order_*), because
     // the kernel's length is set by when its few longest tiles START, not by throughput alone.
     const uint32_t* order;
+    // Tiles that alone would outlast the rest of the launch are taken out of that queue and rendered by
+    // k_render_split, 16 waves per tile (split_tiles[0, *n_split), both written by k_order_place; with order).
+    const uint32_t* split_tiles;
+    const uint32_t* n_split;
     uint32_t* tile_cost;
     unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
 };
@@ -100,10 +104,14 @@ int bounds_blocks(uint64_t n_points);
 // ---- launchers (hvrt_trace.hip) ----
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
-// order <- long tiles (cost > 2.5 x mean) first, the others behind them in natural order;
-// block_count: ceil(n_tiles / 256) + 1 u32 of scratch
-hipError_t launch_order_build(const uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum,
-                              uint32_t* block_count, uint32_t* order, hipStream_t s);
+hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s);
+// split_tiles <- the tiles for k_render_split; order <- the others: long tiles (cost > 2.5 x mean) first, the
+// rest behind them in natural order.  block_count: 2 x (ceil(n_tiles / 256) + 1) u32 of scratch; afterwards
+// block_count[ceil(n_tiles / 256)] is the number of split tiles (0 when may_split is false).  *wants_split
+// (device-visible host memory) <- the number of tiles that qualify for splitting, whatever may_split says.
+hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
+                              bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
+                              uint32_t* wants_split, hipStream_t s);
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n,
                         hvrt_hit* out, unsigned long long* counters, int nearest, hipStream_t s);
 hipError_t launch_quantise_rgb8(const float* rgb /* 16-B aligned */, uint64_t n_values, uint8_t* out /* 4-B aligned */, hipStream_t s);

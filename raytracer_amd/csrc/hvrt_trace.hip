@@ -95,7 +95,13 @@ struct TraceResult {
 // exit of the current voxel -- nothing in a later voxel can beat it, because a triangle hit before that exit
 // is listed in a voxel already visited.  The skip of entries tested one step ago stays valid (their result
 // is remembered in the running minimum).  Same kernels, same data.
-template <bool COUNT, bool INLINE, bool NEAREST>
+//
+// RAYS < 64 (k_render_split, the tiles that alone would outlast the rest of the launch): the wave holds RAYS rays,
+// each on 64 / RAYS lanes ("slices": lane = slice * RAYS + ray).  The slices of a ray walk in lockstep and share
+// out the entries of every list (entry k of a chunk goes to slice k mod 64/RAYS); after the list, the slices'
+// candidates are reduced to the one the sequential loop would have kept -- the highest entry that hit (mode 0),
+// the smallest t, the lower entry on a tie (nearest-hit mode) -- so the result is the same bit for bit.
+template <bool COUNT, bool INLINE, bool NEAREST, int RAYS = 64>
 __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d) {
     const GridParams& g = sc.g;
     TraceResult r;
@@ -215,6 +221,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                             : (last == fsy && g.ny > 1) ? facey : facez;
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         bool found = false;
+        uint32_t bkey = 0;   // RAYS < 64: 1 + list position of this slice's candidate, 0 = none from this list
         {
             // Entries that are also in the list of the voxel the ray just left were tested there one step
             // ago with this very ray and missed (a hit would have ended it), so they are not tested again:
@@ -222,6 +229,10 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
             // read as a 32-entry window starting at b0.  Skipping never changes a result; it halves the
             // records a lane has to fetch (the loop is bound by L1 data return, 40 B per lane and test).
             const uint32_t n = b1 - b0;
+            constexpr uint32_t SLICES = 64u / (uint32_t)RAYS;
+            constexpr uint32_t SLICE_BITS = SLICES == 16u ? 0x00010001u : SLICES == 4u ? 0x11111111u : 0xFFFFFFFFu;
+            static_assert(RAYS == 64 || RAYS == 16 || RAYS == 4, "slice masks are written for 1, 4 and 16 slices");
+            const uint32_t slice_mask = RAYS == 64 ? 0xFFFFFFFFu : SLICE_BITS << ((threadIdx.x & 63u) / (uint32_t)RAYS);
             for (uint32_t c = 0; c < n; c += 32) {
                 const uint32_t base = b0 + c;
                 uint32_t skip = 0;
@@ -231,13 +242,22 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                 }
                 const uint32_t left = n - c;
                 uint32_t todo = ~skip & (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u));
+                if (RAYS < 64) todo &= slice_mask;
                 while (todo) {
                     const uint32_t k = (uint32_t)__builtin_ctz(todo);
                     todo &= todo - 1;
                     const uint32_t j = base + k;
                     float t;
 #ifdef HVRT_DIAG   // diagnostic build only: nt = tests executed, nv = 64 x wave-level test iterations
+#if HVRT_DIAG == 2   // nt = 64 x wave-level iterations in which every active lane tests the SAME entry
+                    if (COUNT) {
+                        const bool lead = (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1;
+                        const bool same = __ballot(j != (uint32_t)__builtin_amdgcn_readfirstlane((int)j)) == 0ull;
+                        if (lead) { r.nv += 64; if (same) r.nt += 64; }
+                    }
+#else
                     if (COUNT) { ++r.nt; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) r.nv += 64; }
+#endif
 #endif
                     if (INLINE) {
                         const float4* __restrict__ rec = sc.ref_rec + 3ull * j;
@@ -247,6 +267,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                         if (ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, t) &&
                             (!NEAREST || t < r.t)) {
                             r.tri = __float_as_uint(reinterpret_cast<const float*>(rec + 2)[1]); r.t = t; found = true;
+                            if (RAYS < 64) bkey = c + k + 1u;
                         }
                     } else {
                         const uint32_t ti = sc.indices[j];
@@ -255,10 +276,21 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                         if (ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, e2z }, o, d, t) &&
                             (!NEAREST || t < r.t)) {
                             r.tri = ti; r.t = t; found = true;
+                            if (RAYS < 64) bkey = c + k + 1u;
                         }
                     }
                 }
             }
+        }
+        if (RAYS < 64) {
+#pragma unroll
+            for (int m = RAYS; m < 64; m <<= 1) {
+                const uint32_t ok = (uint32_t)__shfl_xor((int)bkey, m), otri = (uint32_t)__shfl_xor((int)r.tri, m);
+                const float ot = __shfl_xor(r.t, m);
+                const bool take = NEAREST ? (ot < r.t || (ot == r.t && ok < bkey)) : ok > bkey;
+                if (take) { bkey = ok; r.tri = otri; r.t = ot; }
+            }
+            if (!NEAREST) found = bkey != 0u;
         }
 #ifndef HVRT_DIAG
         if (COUNT) r.nt += b1 - b0;
@@ -318,6 +350,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t tiles_frame = tiles_x * tiles_y;
     const uint32_t n_tiles = tiles_frame * (uint32_t)ra.n_frames;
+    // with an order, the tiles that k_render_split takes are not in this kernel's queue
+    const uint32_t n_queue = ra.order ? n_tiles - *ra.n_split : n_tiles;
     uint64_t tot_nv = 0, tot_nt = 0;
     unsigned long long wave_cost = 0;     // wave-uniform
 
@@ -325,7 +359,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         uint32_t pulled = 0;
         if (lane == 0) {
             pulled = atomicAdd(ra.tile_counter, 1u);
-            if (pulled < n_tiles) {
+            if (pulled >= n_queue) {
+                pulled = 0xFFFFFFFFu;
+            } else {
                 if (ra.order) {
                     pulled = ra.order[pulled];
                 } else {
@@ -399,30 +435,122 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     }
 }
 
+// ---- tiles too long for one wave ------------------------------------------------------------------------
+// A launch cannot end before its longest tile does, and a tile is one wave walking serially dependent look-ups:
+// on the skewed 10 M-triangle scene a few tiles cross voxels with thousands of entries and take 7 ms, whatever
+// the frame size, while the rest of the frame is done in 3.  Tiles that the previous launch measured longer than
+// the whole launch would take on a perfectly filled GPU are therefore rendered by this kernel instead: 16 waves per tile, each with a 2x2 pixel quad of it, every ray on 16 lanes that share out the entries
+// of each list (trace_ray, RAYS = 4).  It runs beside k_render on a second stream.  Items are dealt round-robin
+// with a bounded loop (no queue): they are few and of one kind.
+template <bool COUNT, bool INLINE, bool NEAREST>
+__global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra) {
+    const int lane = threadIdx.x & 63;
+    const int ray = lane & 3, slice = lane >> 2;
+    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
+    const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+    const uint32_t tiles_frame = tiles_x * tiles_y;
+    const uint32_t n_items = *ra.n_split * 16u;
+    const uint32_t wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    uint64_t tot_nv = 0, tot_nt = 0;
+    unsigned long long wave_cost = 0;
+    for (uint32_t item = wave0; item < n_items; item += n_waves) {
+        const long long clk0 = clock64();
+        const uint32_t tile = ra.split_tiles[item >> 4], quad = item & 15u;
+        const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
+        const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
+        const int x = (int)(tx * 8u) + (int)(quad & 3u) * 2 + (ray & 1);
+        const int lr = (int)(ty * 8u) + (int)(quad >> 2) * 2 + (ray >> 1);
+        const int kl = lr / ra.tile_rows;
+        const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
+        const hvrt_camera_frame* __restrict__ cf = ra.frames + fi;
+        const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };
+        const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
+        const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
+        const V3 ver = { cf->vertical[0], cf->vertical[1], cf->vertical[2] };
+        if (x < ra.width && lr < ra.local_rows && y < ra.height) {
+            V3 acc = { 0.0f, 0.0f, 0.0f };
+            uint32_t hit0 = HVRT_MISS; float t0 = FLT_MAX;
+            for (int s = 0; s < ra.spp; ++s) {
+                float jx = 0.0f, jy = 0.0f;
+                if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
+                const float u = ((float)x + jx) / (float)ra.width;
+                const float v = ((float)y + jy) / (float)ra.height;
+                const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
+                const TraceResult r = trace_ray<COUNT, INLINE, NEAREST, 4>(sc, org, d);
+                const V3 c = shade(sc, r, org, v);
+                if (ra.spp == 1) acc = c; else acc = add(acc, c);
+                if (s == 0) { hit0 = r.tri; t0 = r.t; }
+                if (COUNT && slice == 0) { tot_nv += r.nv; tot_nt += r.nt; }
+            }
+            if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+            if (slice == 0) {
+                const size_t p = ((size_t)fi * ra.slab_rows + lr) * ra.width + x;
+                if (ra.rgb) { ra.rgb[3 * p] = acc.x; ra.rgb[3 * p + 1] = acc.y; ra.rgb[3 * p + 2] = acc.z; }
+                if (ra.hit_id) ra.hit_id[p] = hit0;
+                if (ra.t) ra.t[p] = t0;
+            }
+        }
+        const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
+        const uint32_t dc = dt > 0x00FFFFFFull ? 0x00FFFFFFu : (uint32_t)dt;
+        if (lane == 0) atomicAdd(&ra.tile_cost[tile], dc);      // the tile's cost: the sum over its 16 quads
+        wave_cost += dc;
+    }
+    if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
+    if (COUNT && ra.counters) {
+        tot_nv = wave_sum64(tot_nv);
+        tot_nt = wave_sum64(tot_nt);
+        if (lane == 0 && (tot_nv | tot_nt)) {
+            atomicAdd(&ra.counters[0], (unsigned long long)tot_nv);
+            atomicAdd(&ra.counters[1], (unsigned long long)tot_nt);
+        }
+    }
+}
+
 // ---- order of the tile queue: the few long tiles first, the rest as they lie ----------------------------
-// A tile is "long" when the previous launch measured more than 2.5 x the mean tile for it (about 0.5 % of a
-// frame: the silhouette, where rays graze the occupied shell).  Long tiles go to the head of the queue, all
-// others keep their natural order behind them -- neighbours in the queue stay neighbours in the image, which
-// is what keeps the L1 / L2 hit rates (a full sort by cost was measured 7 % slower than no order at all).
-// Stable two-way partition: per-block counts, scan of the counts, placement.
-__device__ __forceinline__ bool tile_is_long(uint32_t c, unsigned long long sum, uint32_t n) {
-    return (unsigned long long)c * 2ull * n > 5ull * sum;       // c > 2.5 * sum / n
+// Three classes from the previous launch's tile durations (sum = their total, n tiles, w wave slots on the GPU):
+//   split  longer than sum / w, the duration of a perfectly balanced launch (a shorter tile that starts first is
+//          not what the launch waits for, and splitting it only adds work: measured): to k_render_split.  The
+//          class is sticky (top bit of the tile's cost word) for as long as the launch shape stays the same, so
+//          that a tile does not flip between the kernels from one launch to the next;
+//   long   more than 2.5 x the mean tile (about 0.5 % of a frame: the silhouette, where rays graze the occupied
+//          shell): to the head of k_render's queue;
+//   the others keep their natural order behind them -- neighbours in the queue stay neighbours in the image,
+//   which is what keeps the L1 / L2 hit rates (a full sort by cost was measured 7 % slower than no order).
+// Stable three-way partition: per-block counts of the first two classes, scan, placement.
+constexpr uint32_t COST_SPLIT_FLAG = 0x80000000u;
+
+__device__ __forceinline__ bool tile_wants_split(uint32_t c, unsigned long long sum, uint32_t slots) {
+    return (c & COST_SPLIT_FLAG) || (unsigned long long)c * slots > sum;
 }
+__device__ __forceinline__ int tile_class(uint32_t c, unsigned long long sum, uint32_t n, uint32_t slots, bool may_split) {
+    if (may_split && tile_wants_split(c, sum, slots)) return 2;
+    return (unsigned long long)(c & ~COST_SPLIT_FLAG) * 2ull * n > 5ull * sum ? 1 : 0;      // c > 2.5 * sum / n
+}
+// block_count: [0, n_blocks] tiles per block that qualify for splitting (allowed or not), [n_blocks + 1,
+// 2 n_blocks + 1] long tiles per block
 __global__ __launch_bounds__(256) void k_order_count(const uint32_t* __restrict__ cost, uint32_t n,
-                                                     const unsigned long long* __restrict__ sum, uint32_t* __restrict__ block_count) {
+                                                     const unsigned long long* __restrict__ sum, uint32_t slots,
+                                                     bool may_split, uint32_t* __restrict__ block_count) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool lng = i < n && tile_is_long(cost[i], *sum, n);
-    __shared__ uint32_t w[4];
-    const unsigned long long m = __ballot(lng);
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    const bool wants = i < n && tile_wants_split(cost[i], *sum, slots);
+    const int cls = i < n ? tile_class(cost[i], *sum, n, slots, may_split) : 0;
+    __shared__ uint32_t w[2][4];
+    const unsigned long long m2 = __ballot(wants), m1 = __ballot(cls == 1);
+    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = (uint32_t)__popcll(m2); w[1][threadIdx.x >> 6] = (uint32_t)__popcll(m1); }
     __syncthreads();
-    if (threadIdx.x == 0) block_count[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+    if (threadIdx.x < 2) block_count[threadIdx.x * (gridDim.x + 1) + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
 }
-// block_count <- exclusive scan; block_count[n_blocks] <- total (one workgroup)
-__global__ __launch_bounds__(1024) void k_order_scan(uint32_t* __restrict__ block_count, uint32_t n_blocks) {
+// each of the two count arrays <- its exclusive scan, [n_blocks] <- its total (one workgroup per array).  The
+// number of tiles that qualify for splitting goes to *wants_split (pinned host memory, one store; the host reads
+// it, without waiting, to decide whether the NEXT launch gets a k_render_split); when this launch may not split,
+// the first array is cleared instead -- nothing is split.
+__global__ __launch_bounds__(1024) void k_order_scan(uint32_t* __restrict__ block_counts, uint32_t n_blocks, bool may_split,
+                                                     uint32_t* __restrict__ wants_split) {
+    uint32_t* __restrict__ block_count = block_counts + blockIdx.x * (n_blocks + 1);
+    const bool keep = blockIdx.x != 0 || may_split;
     __shared__ uint32_t sh[1024];
     const uint32_t per = (n_blocks + 1023u) / 1024u;
-    const uint32_t b = threadIdx.x * per, e = b + per < n_blocks ? b + per : n_blocks;
+    const uint32_t b0 = threadIdx.x * per, b = b0 < n_blocks ? b0 : n_blocks, e = b + per < n_blocks ? b + per : n_blocks;
     uint32_t sum = 0;
     for (uint32_t i = b; i < e; ++i) sum += block_count[i];
     sh[threadIdx.x] = sum;
@@ -434,23 +562,34 @@ __global__ __launch_bounds__(1024) void k_order_scan(uint32_t* __restrict__ bloc
         __syncthreads();
     }
     uint32_t run = sh[threadIdx.x] - sum;
-    for (uint32_t i = b; i < e; ++i) { const uint32_t v = block_count[i]; block_count[i] = run; run += v; }
-    if (threadIdx.x == 1023) block_count[n_blocks] = sh[1023];
+    for (uint32_t i = b; i < e; ++i) { const uint32_t v = block_count[i]; block_count[i] = keep ? run : 0u; run += v; }
+    if (threadIdx.x == 1023) {
+        block_count[n_blocks] = keep ? sh[1023] : 0u;
+        if (blockIdx.x == 0) *wants_split = sh[1023];
+    }
 }
-__global__ __launch_bounds__(256) void k_order_place(const uint32_t* __restrict__ cost, uint32_t n,
-                                                     const unsigned long long* __restrict__ sum,
+// order[0, n - n_split): k_render's queue; split_tiles[0, n_split): k_render_split's tiles, whose cost words are
+// reset to the bare flag (that kernel adds its quads' durations to them)
+__global__ __launch_bounds__(256) void k_order_place(uint32_t* __restrict__ cost, uint32_t n,
+                                                     const unsigned long long* __restrict__ sum, uint32_t slots, bool may_split,
                                                      const uint32_t* __restrict__ block_count, uint32_t n_blocks,
-                                                     uint32_t* __restrict__ order) {
+                                                     uint32_t* __restrict__ order, uint32_t* __restrict__ split_tiles) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool lng = i < n && tile_is_long(cost[i], *sum, n);
-    __shared__ uint32_t w[4];
-    const unsigned long long m = __ballot(lng);
+    const int cls = i < n ? tile_class(cost[i], *sum, n, slots, may_split) : 0;
+    __shared__ uint32_t w[2][4];
+    const unsigned long long m2 = __ballot(cls == 2), m1 = __ballot(cls == 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) w[wv] = (uint32_t)__popcll(m);
+    if (lane == 0) { w[0][wv] = (uint32_t)__popcll(m2); w[1][wv] = (uint32_t)__popcll(m1); }
     __syncthreads();
-    uint32_t before = block_count[blockIdx.x] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-    for (int k = 0; k < wv; ++k) before += w[k];
-    if (i < n) order[lng ? before : block_count[n_blocks] + (i - before)] = i;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t before2 = block_count[blockIdx.x] + (uint32_t)__popcll(m2 & below);
+    uint32_t before1 = block_count[n_blocks + 1 + blockIdx.x] + (uint32_t)__popcll(m1 & below);
+    for (int k = 0; k < wv; ++k) { before2 += w[0][k]; before1 += w[1][k]; }
+    if (i >= n) return;
+    const uint32_t n_long = block_count[2 * n_blocks + 1];
+    if (cls == 2) { split_tiles[before2] = i; cost[i] = COST_SPLIT_FLAG; }
+    else if (cls == 1) order[before1] = i;
+    else order[n_long + (i - before2 - before1)] = i;
 }
 
 // traceRay batch: one lane per ray, RayHit records out (OctreeLikeRayTracer.cpp:124-126, :283-288).
@@ -551,12 +690,35 @@ hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hi
     return hipGetLastError();
 }
 
-hipError_t launch_order_build(const uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum,
-                              uint32_t* block_count, uint32_t* order, hipStream_t s) {
-    const uint32_t blocks = (n_tiles + 255) / 256;
-    k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, block_count);
-    k_order_scan<<<1, 1024, 0, s>>>(block_count, blocks);
-    k_order_place<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, block_count, blocks, order);
+hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s) {
+    const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
+    if (n_tiles == 0 || !ra.order) return hipSuccess;
+    uint64_t blocks = n_tiles * 4;                         // 16 waves per tile, were every tile split
+    const uint64_t cap = (uint64_t)n_cus * 4;
+    if (blocks > cap) blocks = cap;
+    const bool il = sc.ref_rec != nullptr;
+    const unsigned nb = (unsigned)blocks;
+#define HVRT_LAUNCH(C, I, N) k_render_split<C, I, N><<<nb, 256, 0, s>>>(sc, ra)
+    if (ra.nearest) {
+        if (ra.counters) { if (il) HVRT_LAUNCH(true, true, true); else HVRT_LAUNCH(true, false, true); }
+        else             { if (il) HVRT_LAUNCH(false, true, true); else HVRT_LAUNCH(false, false, true); }
+    } else {
+        if (ra.counters) { if (il) HVRT_LAUNCH(true, true, false); else HVRT_LAUNCH(true, false, false); }
+        else             { if (il) HVRT_LAUNCH(false, true, false); else HVRT_LAUNCH(false, false, false); }
+    }
+#undef HVRT_LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
+                              bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
+                              uint32_t* wants_split, hipStream_t s) {
+    const unsigned blocks = (n_tiles + 255u) / 256u;
+    const uint32_t slots = (uint32_t)n_cus * 20u;          // k_render runs 5 waves per SIMD
+    may_split = may_split && n_tiles <= 0x0FFFFFFFu;       // 16 items per tile in a 32-bit count
+    k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count);
+    k_order_scan<<<2, 1024, 0, s>>>(block_count, blocks, may_split, wants_split);
+    k_order_place<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count, blocks, order, split_tiles);
     return hipGetLastError();
 }
 

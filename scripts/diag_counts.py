@@ -7,7 +7,11 @@ import numpy as np
 import raytracer_amd as ra
 from raytracer_amd import capi, meshgen
 
-tris, g, W, H = meshgen.cube_sphere(289), 256, 3840, 2160
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+if which == "c3":
+    tris, g, W, H = meshgen.skewed_statue(289, 2100), 512, 3840, 2160
+else:
+    tris, g, W, H = meshgen.cube_sphere(289), 256, 3840, 2160
 ctx = ra.Context(0)
 ctx.set_mesh(tris)
 mn, mx = ctx.mesh_bounds()
@@ -17,5 +21,6 @@ pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
 cam = capi.make_camera_frame(pos, la, up, fov, asp)
 cnt = ctx.render(cam, W, H)[3]
 n = W * H
+print(f"[DIAG=2: second/first = share of wave iterations whose lanes all test one entry: {cnt[1]/max(cnt[0],1):.3f}]")
 print(f"tests executed per ray {cnt[1]/n:.2f}; wave test iterations per ray-slot {cnt[0]/n:.2f} (x64 lanes)")
 ctx.close()

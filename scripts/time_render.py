@@ -18,6 +18,8 @@ elif which == "c4":
 elif which == "small":
     tris, g, W, H = meshgen.cube_sphere(58), 50, 800, 600
 spp = 16 if which == "c4" else 1
+if os.environ.get("HVRT_TIME_WH"):          # e.g. 1920x1080: same scene, other frame size
+    W, H = (int(v) for v in os.environ["HVRT_TIME_WH"].split("x"))
 ctx = ra.Context(0)
 import os
 if os.environ.get("HVRT_TIME_MODE"):          # 1: nearest-hit mode (hvrt_set_mode)

@@ -215,6 +215,27 @@ def test_batch_launch_equals_single_launches_and_order_changes_nothing(ctx, n_pa
         ctx.render_batch_part_device(cams * 9, W, H, 1, 0, tile_rows, part, n_parts, slab, d_rgb=batch.data_ptr())
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_split_tiles_change_nothing(ctx, mode):
+    """From the second launch of a shape on, tiles that took longer than a balanced launch would are rendered by
+    k_render_split (2x2 pixel quads, every ray on 16 lanes that share out each list).  A 640x360 frame of a scene
+    with long lists has both kinds of tiles; a 96x64 frame has only split ones.  Frames, hit ids, t and the
+    counters of launches 1..4 are the oracle's, in both traversal modes, with 1 and 3 samples per pixel."""
+    tris = meshgen.skewed_statue(24, 120)
+    sc, mn, mx = setup_scene(ctx, tris, (32, 32, 32))
+    try:
+        ctx.set_mode(mode)
+        sc.set_mode(mode, mx)
+        for (W, H, spp) in ((640, 360, 1), (96, 64, 3)):
+            fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
+            exp = sc.render(fr, W, H, threads=16, spp=spp, seed=5)
+            for launch in range(4):
+                assert_frames_equal(ctx.render(fr, W, H, spp=spp, seed=5), exp)
+    finally:
+        ctx.set_mode(0)
+        sc.set_mode(0)
+
+
 def _quantise_ref(rgb):
     """ImageSaver.h:28-33: (uint8_t)clamp(c * 255.0f, 0.0f, 255.0f), truncating; NaN -> 0 (documented)."""
     v = rgb.astype(np.float32) * np.float32(255.0)
@@ -376,10 +397,11 @@ def _rows_against_oracle(ctx, tris, g, W, H, rows, spp=1, seed=0, launches=1):
 
 def test_config3_like_full_size_render_rows(ctx):
     """BASELINE config 3 shape (9.8 M triangles, dense patch with 3706-entry lists, 512^3, 3840x2160): every
-    24th row, and every 2nd row across the patch, bit for bit against the oracle; second launch (ordered)."""
+    24th row, and every 2nd row across the patch, bit for bit against the oracle; third launch (the second is
+    ordered and hands the tiles that cross the patch to k_render_split, the third builds on the second's clocks)."""
     W, H = 3840, 2160
     rows = sorted(set(range(0, H, 24)) | set(range(1000, 1160, 2)))
-    _rows_against_oracle(ctx, meshgen.skewed_statue(289, 2100), 512, W, H, rows, launches=2)
+    _rows_against_oracle(ctx, meshgen.skewed_statue(289, 2100), 512, W, H, rows, launches=3)
 
 
 def test_config4_8k_16spp_rows(ctx):
