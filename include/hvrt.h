@@ -215,7 +215,8 @@ int hvrt_render_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int w
  * Scheduling note for both forms: each launch records the duration of every 8x8 tile, and the next launch
  * of the same shape (image size, partition, n_frames, spp) on the same scene pulls its tiles longest-first.
  * A launch without such history takes the rows of tiles from the middle of the frame outwards.  Only the order
- * of work changes, never a result; HVRT_TILE_ORDER=0 in the environment disables the use of history. */
+ * of work changes, never a result; HVRT_TILE_ORDER=0 in the environment disables the use of history
+ * (HVRT_TILE_SPLIT=0 only the hand-over of over-long tiles to the 16-waves-per-tile kernel). */
 #define HVRT_MAX_BATCH_FRAMES 32
 int hvrt_render_batch_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frames, int n_frames,
                                   int width, int height, int spp, uint32_t seed,

@@ -185,7 +185,7 @@ int check_grid_args(hvrt_ctx* c, int nx, int ny, int nz, const float* mn, const 
     if (nx < 1 || ny < 1 || nz < 1) return fail(c, HVRT_ERR_INVALID, "grid: dimensions must be >= 1 (got %d x %d x %d)", nx, ny, nz);
     if (nx > 65536 || ny > 65536 || nz > 65536) return fail(c, HVRT_ERR_INVALID, "grid: at most 65536 voxels per axis");
     uint64_t nvox = (uint64_t)nx * ny * nz;
-    if (nvox > 0xFFFFFFFFull - 2 * SCAN_CHUNK) return fail(c, HVRT_ERR_INVALID, "grid: at most 2^32 - 8192 voxels");
+    if (nvox > 0xFFFFFFFFull - 2 * SCAN_CHUNK) return fail(c, HVRT_ERR_INVALID, "grid: at most 2^32 - 65536 voxels");
     return HVRT_OK;
 }
 
@@ -494,13 +494,12 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(uint64_t), s));
     HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, cnt_of(c), c->ranges, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    HIP_TRY(c, launch_scan_reduce(cnt_of(c), n_chunks, c->block_sums, c->stats, s));
-    HIP_TRY(c, launch_scan_sums(c->block_sums, n_chunks, c->stats, s));
-    HIP_TRY(c, launch_scan_apply(cnt_of(c), n_chunks, c->block_sums, s));
+    HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, s));
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    uint64_t h_stats[4];
+    uint64_t h_stats[6];
     HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (h_stats[5]) return fail(c, HVRT_ERR_HIP, "build_grid: the offset scan gave up waiting for a chunk (device fault?)");
     const uint64_t total = h_stats[0];
     if (total > 0xFFFFFFFFull)
         return fail(c, HVRT_ERR_OVERFLOW, "build_grid: %llu triangle references exceed the u32 CSR", (unsigned long long)total);

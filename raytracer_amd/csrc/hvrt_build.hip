@@ -206,119 +206,97 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
     return v;
 }
 
-// phase A: per-chunk sum (+ occupancy statistics, VoxelizationResult::occupied_count)
-__global__ __launch_bounds__(256) void k_scan_reduce(const uint4* __restrict__ cnt4, uint64_t* __restrict__ block_sums,
-                                                     uint64_t* __restrict__ stats) {
-    const uint64_t c = blockIdx.x;
-    const uint4* p = cnt4 + c * (SCAN_CHUNK / 4);
-    uint64_t sum = 0; uint32_t occ = 0, mx = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint4 v = p[j * 256 + threadIdx.x];
-        sum += (uint64_t)v.x + v.y + v.z + v.w;
-        occ += (v.x > 0) + (v.y > 0) + (v.z > 0) + (v.w > 0);
-        uint32_t m = v.x > v.y ? v.x : v.y, n = v.z > v.w ? v.z : v.w;
-        m = m > n ? m : n;
-        mx = mx > m ? mx : m;
-    }
-    __shared__ uint64_t s_sum[4], s_occ[4];
-    __shared__ uint32_t s_mx[4];
-    sum = wave_sum64(sum);
-    uint64_t occ64 = wave_sum64(occ);
-    mx = wave_max32(mx);
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_sum[w] = sum; s_occ[w] = occ64; s_mx[w] = mx; }
+// Exclusive scan of the counters, in place, in ONE pass over the array (chained scan with decoupled look-back):
+// a workgroup takes the next chunk (a ticket, so that every chunk before it has already started), scans its 32768
+// counters in registers, publishes the chunk total, adds up the totals of the chunks before it -- looking back
+// 64 chunks at a time until it meets one whose inclusive prefix is already known -- publishes its own inclusive
+// prefix and writes the offsets.  4 bytes read and 4 written per voxel; the reduce / scan-of-sums / apply scheme
+// it replaces read the array twice and had a single-workgroup kernel in the middle.
+// Each wave owns 2048 consecutive counters and walks them in eight fully coalesced 1-KiB rows (lane i holds
+// counters 4i..4i+3 of the row), scanning each row with wave shuffles and carrying the row total forward.
+// status[c]: bits 63..62 = 0 nothing yet, 1 chunk total, 2 inclusive prefix; bits 61..0 the value (one 64-bit
+// word, so flag and value arrive together).  A wait is bounded: a chunk that never shows up ends the wait,
+// raises stats[5] and the build is reported as failed -- the kernel cannot hang.
+constexpr uint64_t ST_AGG = 1ull << 62, ST_PFX = 2ull << 62, ST_VALUE = (1ull << 62) - 1ull;
+constexpr uint32_t ST_SPIN_LIMIT = 1u << 22;
+constexpr int SCAN_WAVES = SCAN_CHUNK / 2048;       // 16 waves of 2048 counters each
+__global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cnt4, uint64_t* __restrict__ status,
+                                                          uint64_t* __restrict__ aux, uint64_t* __restrict__ stats) {
+    __shared__ uint32_t s_chunk, s_w[SCAN_WAVES], s_occ[SCAN_WAVES], s_mx[SCAN_WAVES];
+    __shared__ uint64_t s_base;
+    if (threadIdx.x == 0) s_chunk = atomicAdd(reinterpret_cast<uint32_t*>(stats + 6), 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t ts = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        uint64_t to = s_occ[0] + s_occ[1] + s_occ[2] + s_occ[3];
-        uint32_t tm = s_mx[0];
-        for (int i = 1; i < 4; ++i) tm = s_mx[i] > tm ? s_mx[i] : tm;
-        block_sums[c] = ts;
-        // occupied count and longest list of the chunk ride along (no same-address atomics: a quarter of a
-        // million of them serialised in L2 and cost four times the 4-GB read itself)
-        block_sums[gridDim.x + c] = to | ((uint64_t)tm << 32);
-    }
-}
-
-// phase B: exclusive scan of the chunk sums by one workgroup.  Each of the 16 waves owns a contiguous run of
-// sums and walks it in rows of 64 (one coalesced 512-byte read per row): wave scan per row, carry between
-// rows; the 16 run totals meet once in LDS.  The per-chunk (occupied, longest) pairs are folded on the way.
-__device__ __forceinline__ uint64_t wave_inclusive_scan64(uint64_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
-    return v;
-}
-__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ block_sums, uint64_t n,
-                                                    uint64_t* __restrict__ stats) {
-    __shared__ uint64_t s_tot[16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t per = ((n + 15) / 16 + 63) / 64 * 64;          // run length per wave, whole rows
-    const uint64_t b = (uint64_t)w * per;
-    const uint64_t e = b + per < n ? b + per : n;
-    uint64_t occ = 0, total = 0;
-    uint32_t mx = 0;
-    for (uint64_t r = b; r < e; r += 64) {                        // pass 1: run total, occupancy, longest list
-        const uint64_t i = r + lane;
-        if (i < e) {
-            total += block_sums[i];
-            const uint64_t aux = block_sums[n + i];
-            occ += aux & 0xFFFFFFFFull;
-            const uint32_t m = (uint32_t)(aux >> 32);
-            mx = m > mx ? m : mx;
-        }
-    }
-    total = wave_sum64(total);
-    occ = wave_sum64(occ);
-    mx = wave_max32(mx);
-    if (lane == 0) {
-        s_tot[w] = total;
-        if (occ) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)occ);
-        if (mx) atomicMax((unsigned long long*)&stats[2], (unsigned long long)mx);
-    }
-    __syncthreads();
-    uint64_t carry = 0;
-    for (int k = 0; k < w; ++k) carry += s_tot[k];
-    if (threadIdx.x == 1023) { uint64_t t = 0; for (int k = 0; k < 16; ++k) t += s_tot[k]; stats[0] = t; }
-    for (uint64_t r = b; r < e; r += 64) {                        // pass 2: exclusive prefixes, in place
-        const uint64_t i = r + lane;
-        const uint64_t v = i < e ? block_sums[i] : 0;
-        const uint64_t inc = wave_inclusive_scan64(v);
-        if (i < e) block_sums[i] = carry + inc - v;
-        carry += __shfl(inc, 63);
-    }
-}
-
-// phase C: per-chunk exclusive scan, in place.  Each wave owns 1024 consecutive counters and walks them in
-// four fully coalesced 1-KiB rows (lane i holds counters 4i..4i+3 of the row), scanning each row with wave
-// shuffles and carrying the row total forward; the four wave totals meet once in LDS.
-__global__ __launch_bounds__(256) void k_scan_apply(uint4* __restrict__ cnt4, const uint64_t* __restrict__ block_sums) {
-    const uint64_t c = blockIdx.x;
+    const uint64_t c = s_chunk;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint4* p = cnt4 + c * (SCAN_CHUNK / 4) + w * 256 + lane;
-    uint4 v[4];
-    uint32_t excl[4];
+    uint4* p = cnt4 + c * (SCAN_CHUNK / 4) + w * 512 + lane;
+    uint4 v[8];
+    uint32_t excl[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = p[k * 64];
-    uint32_t carry = 0;
+    for (int k = 0; k < 8; ++k) v[k] = p[k * 64];
+    uint32_t carry = 0, occ = 0, mx = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const uint32_t tot = v[k].x + v[k].y + v[k].z + v[k].w;
         const uint32_t inc = wave_inclusive_scan(tot);
         excl[k] = carry + inc - tot;
         carry += __shfl(inc, 63);
+        occ += (v[k].x > 0) + (v[k].y > 0) + (v[k].z > 0) + (v[k].w > 0);
+        const uint32_t m = v[k].x > v[k].y ? v[k].x : v[k].y, n = v[k].z > v[k].w ? v[k].z : v[k].w;
+        const uint32_t mm = m > n ? m : n;
+        mx = mx > mm ? mx : mm;
     }
-    __shared__ uint32_t s_w[4];
-    if (lane == 0) s_w[w] = carry;
+    occ = (uint32_t)wave_sum64(occ);
+    mx = wave_max32(mx);
+    if (lane == 0) { s_w[w] = carry; s_occ[w] = occ; s_mx[w] = mx; }
     __syncthreads();
-    uint32_t base = (uint32_t)block_sums[c];
-    for (int i = 0; i < w; ++i) base += s_w[i];
+    if (w == 0) {
+        // wave 0: the waves' totals -> their exclusive prefixes (left in s_w), chunk total, statistics
+        const uint32_t wt = lane < SCAN_WAVES ? s_w[lane] : 0u;
+        const uint32_t winc = wave_inclusive_scan(wt);
+        const uint64_t total = __shfl(winc, 63);
+        const uint32_t tocc = (uint32_t)wave_sum64(lane < SCAN_WAVES ? s_occ[lane] : 0u);
+        const uint32_t tmx = wave_max32(lane < SCAN_WAVES ? s_mx[lane] : 0u);
+        if (lane < SCAN_WAVES) s_w[lane] = winc - wt;
+        if (lane == 0) {
+            // occupied count and longest list of the chunk, reduced by k_scan_stats (tens of thousands of
+            // same-address atomics from here would serialise in L2)
+            aux[c] = (uint64_t)tocc | ((uint64_t)tmx << 32);
+            __hip_atomic_store(&status[c], (c == 0 ? ST_PFX : ST_AGG) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint64_t before = 0;          // sum of the chunks before this one (lane 0)
+        bool gave_up = false;
+        if (c > 0) {
+            long long pos = (long long)c - 1;
+            for (;;) {
+                const long long i = pos - lane;
+                uint64_t word = ST_PFX;                       // in front of the array: an empty prefix
+                if (i >= 0) {
+                    uint32_t spins = 0;
+                    for (;;) {
+                        word = __hip_atomic_load(&status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((word >> 62) != 0ull) break;
+                        if (++spins >= ST_SPIN_LIMIT) { gave_up = true; word = ST_PFX; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                const unsigned long long pfx = __ballot((word >> 62) == 2ull);
+                const int first = pfx ? __ffsll((long long)pfx) - 1 : 64;      // nearest chunk with a known prefix
+                before += wave_sum64(lane <= first ? (word & ST_VALUE) : 0ull);
+                if (pfx) break;
+                pos -= 64;
+            }
+        }
+        if (__ballot(gave_up) != 0ull && lane == 0) atomicOr((unsigned long long*)&stats[5], 1ull);
+        if (lane == 0) {
+            if (c > 0) __hip_atomic_store(&status[c], ST_PFX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == gridDim.x - 1) stats[0] = before + total;
+            s_base = before;
+        }
+    }
+    __syncthreads();
+    const uint32_t base = (uint32_t)s_base + s_w[w];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 8; ++k) {
         uint32_t run = base + excl[k];
         uint4 o;
         o.x = run; run += v[k].x;
@@ -326,6 +304,22 @@ __global__ __launch_bounds__(256) void k_scan_apply(uint4* __restrict__ cnt4, co
         o.z = run; run += v[k].z;
         o.w = run;
         p[k * 64] = o;
+    }
+}
+// occupied voxels and longest list: reduction of the per-chunk pairs
+__global__ __launch_bounds__(256) void k_scan_stats(const uint64_t* __restrict__ aux, uint64_t n, uint64_t* __restrict__ stats) {
+    uint64_t occ = 0; uint32_t mx = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t a = aux[i];
+        occ += a & 0xFFFFFFFFull;
+        const uint32_t m = (uint32_t)(a >> 32);
+        mx = m > mx ? m : mx;
+    }
+    occ = wave_sum64(occ);
+    mx = wave_max32(mx);
+    if ((threadIdx.x & 63) == 0) {
+        if (occ) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)occ);
+        if (mx) atomicMax((unsigned long long*)&stats[2], (unsigned long long)mx);
     }
 }
 
@@ -812,19 +806,13 @@ hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, u
     return hipGetLastError();
 }
 
-hipError_t launch_scan_reduce(const uint32_t* cnt, uint64_t n_chunks, uint64_t* block_sums, uint64_t* stats,
-                              hipStream_t s) {
-    k_scan_reduce<<<(unsigned)n_chunks, 256, 0, s>>>((const uint4*)cnt, block_sums, stats);
-    return hipGetLastError();
-}
-
-hipError_t launch_scan_sums(uint64_t* block_sums, uint64_t n_chunks, uint64_t* stats, hipStream_t s) {
-    k_scan_sums<<<1, 1024, 0, s>>>(block_sums, n_chunks, stats);
-    return hipGetLastError();
-}
-
-hipError_t launch_scan_apply(uint32_t* cnt, uint64_t n_chunks, const uint64_t* block_sums, hipStream_t s) {
-    k_scan_apply<<<(unsigned)n_chunks, 256, 0, s>>>((uint4*)cnt, block_sums);
+hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, hipStream_t s) {
+    // status words must start empty; the ticket (stats[6]) and the failure flag (stats[5]) were zeroed with stats
+    hipError_t e = hipMemsetAsync(status_aux, 0, n_chunks * sizeof(uint64_t), s);
+    if (e != hipSuccess) return e;
+    k_scan<<<(unsigned)n_chunks, SCAN_WAVES * 64, 0, s>>>((uint4*)cnt, status_aux, status_aux + n_chunks, stats);
+    const uint64_t blocks = (n_chunks + 2047) / 2048;
+    k_scan_stats<<<(unsigned)(blocks > 256 ? 256 : blocks), 256, 0, s>>>(status_aux + n_chunks, n_chunks, stats);
     return hipGetLastError();
 }
 

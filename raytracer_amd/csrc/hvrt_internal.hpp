@@ -75,15 +75,15 @@ struct RenderArgs {
 };
 
 // ---- launchers (hvrt_build.hip) ----
-constexpr int SCAN_CHUNK = 4096;  // elements per scan block (256 threads x 16)
+constexpr int SCAN_CHUNK = 32768;  // counters per scan workgroup (1024 threads x 32)
 
 hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t n_tris, hipStream_t s);
 hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
                         uint32_t* ranges, hipStream_t s);
-hipError_t launch_scan_reduce(const uint32_t* cnt, uint64_t n_chunks, uint64_t* block_sums, uint64_t* stats,
-                              hipStream_t s);
-hipError_t launch_scan_sums(uint64_t* block_sums, uint64_t n_chunks, uint64_t* stats, hipStream_t s);
-hipError_t launch_scan_apply(uint32_t* cnt, uint64_t n_chunks, const uint64_t* block_sums, hipStream_t s);
+// in-place exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64 of scratch.
+// stats[0] <- total, stats[1] += occupied voxels, stats[2] <- longest list, stats[5] != 0: the scan gave up
+// (stats[5], stats[6] must be zero on entry)
+hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, hipStream_t s);
 hipError_t launch_fill(const uint32_t* ranges, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
                        uint32_t* indices_unsorted, uint32_t* vox_of, hipStream_t s);
 hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, uint64_t n_refs,

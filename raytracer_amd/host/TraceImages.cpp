@@ -118,6 +118,7 @@ std::unique_ptr<IRayTracer> TraceImages::createRayTracer(VoxelGrid& voxelGrid, R
 
 void TraceImages::renderAndSave(Loaded& l, const Camera& cam, const std::string& filename, RayTracingMethod) {
     HipVoxelRayTracer tracer(l.scene);
+    tracer.setNearestHit(nearestHit);
     auto t0 = std::chrono::steady_clock::now();
     lastPixels = tracer.render(cam, imageWidth, imageHeight);
     lastHitIds = tracer.lastHitIds();
@@ -157,6 +158,7 @@ void TraceImages::TraceImageMultiView(std::string gridFileLocation, std::string 
         std::vector<Camera> cams;
         for (const auto& vs : views) cams.push_back(setupCameraWithView(l.grid, vs.first));
         HipVoxelRayTracer tracer(l.scene);
+        tracer.setNearestHit(nearestHit);
         auto tv = std::chrono::steady_clock::now();
         const auto frames = tracer.renderViewsRgb8(cams, imageWidth, imageHeight);
         lastPixels.clear();

@@ -38,6 +38,8 @@ public:
     int gridResolution = 50;
     int imageWidth = 800, imageHeight = 600;
     std::string outputDirectory = "";
+    // false: the reference's traversal.  true: HipVoxelRayTracer::setNearestHit (an extension, off by default)
+    bool nearestHit = false;
     // last frame rendered (for callers / tests that want the pixels, not the file)
     std::vector<cg_datastructures::Vec3> lastPixels;
     std::vector<unsigned int> lastHitIds;

@@ -1,7 +1,7 @@
 // trace_image -- command-line front end of the host mirror (the reference's main() has hard-coded
 // Windows paths, RayTracer.cpp:8-44; this takes them as arguments).
 //   trace_image render <in.stl|in.voxgrid> <out.png|.ppm> [--method hip|voxel_dda|art|octree] [--multiview]
-//                      [--grid N] [--size WxH] [--outdir DIR] [--dump-raw FILE]
+//                      [--grid N] [--size WxH] [--outdir DIR] [--dump-raw FILE] [--nearest] [--quiet]
 //   trace_image stl-info <in.stl> <out.bin>        (CPU only: vertex / triangle numbering of the loader)
 //   trace_image save-voxgrid <in.stl> <out.voxgrid> [--grid N]
 #include <cstdio>
@@ -22,7 +22,7 @@ int main(int argc, char** argv) {
     if (argc < 4) return usage();
     const std::string cmd = argv[1], in = argv[2], out = argv[3];
     RayTracingMethod method = RayTracingMethod::HIP_VOXEL;
-    bool multiview = false;
+    bool multiview = false, nearest = false;
     int grid = 50, W = 800, H = 600;
     std::string outdir, dump;
     for (int i = 4; i < argc; ++i) {
@@ -40,6 +40,7 @@ int main(int argc, char** argv) {
         else if (a == "--size") { if (std::sscanf(next().c_str(), "%dx%d", &W, &H) != 2) return usage(); }
         else if (a == "--outdir") outdir = next();
         else if (a == "--dump-raw") dump = next();
+        else if (a == "--nearest") nearest = true;
         else if (a == "--quiet") Logger::setLevel(hvrt_log::ERROR);
         else return usage();
     }
@@ -68,6 +69,7 @@ int main(int argc, char** argv) {
             ti.imageWidth = W;
             ti.imageHeight = H;
             ti.outputDirectory = outdir;
+            ti.nearestHit = nearest;
             if (multiview) ti.TraceImageMultiView(in, out, method);
             else ti.TraceImage(in, out, method);
             if (ti.lastOk && !dump.empty()) {

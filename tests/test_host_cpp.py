@@ -162,6 +162,23 @@ def test_trace_image_multiview_and_voxgrid_round_trip(tmp_path):
 
 
 @pytest.mark.gpu
+def test_trace_image_nearest_hit_knob(tmp_path):
+    """TraceImages::nearestHit / trace_image --nearest: the frame is the oracle's mode-1 frame (an extension; the
+    default stays the reference's traversal, checked above)."""
+    stl = os.path.join(G, "fixture_binary.stl")
+    dump = str(tmp_path / "raw.bin")
+    run("render", stl, "n.ppm", "--outdir", str(tmp_path) + "/", "--size", "320x240", "--grid", "20", "--nearest",
+        "--dump-raw", dump, "--quiet")
+    rgb, hit = read_dump(dump, 320, 240)
+    (orgb0, ohit0, _, _), sc, mn, mx = oracle_frame_for_stl(stl, 20, 320, 240)
+    sc.set_mode(1, mx)
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, "front")
+    orgb, ohit, _, _ = sc.render(oracle.camera_frame(pos, la, up, fov, asp), 320, 240, threads=8)
+    assert np.array_equal(hit, ohit) and np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32))
+    assert not np.array_equal(ohit, ohit0)          # the two traversals do differ on this scene
+
+
+@pytest.mark.gpu
 def test_trace_image_error_behaviour(tmp_path):
     stl = os.path.join(G, "fixture_binary.stl")
     # unsupported extension: the reference throws "Unsupported file format", TraceImage logs and returns
