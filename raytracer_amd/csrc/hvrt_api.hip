@@ -76,6 +76,8 @@ struct hvrt_ctx {
     uint32_t* tile_order = nullptr; uint64_t tile_order_capacity = 0;
     uint32_t* order_blocks = nullptr; uint64_t order_blocks_capacity = 0;
     uint32_t* split_tiles = nullptr; uint64_t split_tiles_capacity = 0;
+    uint32_t* abandoned = nullptr; uint64_t abandoned_capacity = 0;
+    long long abort_clocks = 2400000;   // ~1 ms; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
     // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
     // Read without waiting -- a stale answer only delays the switch by a launch.  Starts at "some".
@@ -331,6 +333,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_TILE_ABORT_US")) c->abort_clocks = atoll(v) > 0 ? atoll(v) * 2400 : (1ll << 62);
     if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_i, 2048 * 6 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
@@ -345,7 +348,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
-                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles,
+                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
@@ -720,6 +723,7 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     if (int r = ensure<uint32_t>(c, c->tile_cost, c->tile_cost_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->tile_order, c->tile_order_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->split_tiles, c->split_tiles_capacity, n_tiles)) return r;
+    if (int r = ensure<uint32_t>(c, c->abandoned, c->abandoned_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, 2 * (order_blocks + 1))) return r;
     const bool reuse = c->adaptive_order && c->cost_valid && !grew && memcmp(key, c->cost_key, sizeof key) == 0;
 
@@ -735,11 +739,14 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     ra.order = reuse ? c->tile_order : nullptr;
     ra.split_tiles = c->split_tiles;
     ra.n_split = c->order_blocks + order_blocks;
+    ra.abandoned = c->abandoned;
+    ra.n_abandoned = c->tile_counter + 1;
+    ra.abort_clocks = c->abort_clocks;
     ra.tile_cost = c->tile_cost;
     unsigned long long* prev_sum = c->cost_sum + c->cost_parity;
     c->cost_parity ^= 1;
     ra.cost_sum = c->cost_sum + c->cost_parity;
-    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 2 * sizeof(uint32_t), s));   // queue head, abandoned count
     HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     if (reuse && n_tiles) {
@@ -753,10 +760,20 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
             HIP_TRY(c, launch_render_split(scene_of(c), ra, c->n_cus, c->aux_stream));
             HIP_TRY(c, hipEventRecord(c->ev_split_join, c->aux_stream));
         }
-        HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, s));
+        HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, false, s));
         if (may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
     } else {
-        HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, s));
+        // no history: the kernel may give up on over-long tiles; k_render_split renders those behind it (none,
+        // as a rule: it then finds an empty list and ends)
+        const bool abortable = c->adaptive_split && n_tiles != 0;
+        HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, abortable, s));
+        if (abortable) {
+            RenderArgs rb = ra;
+            rb.order = c->tile_order;           // any non-null value: "there is a list"
+            rb.split_tiles = c->abandoned;
+            rb.n_split = ra.n_abandoned;
+            HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s));
+        }
     }
     HIP_TRY(c, hipEventRecord(c->ev[7], s));
     memcpy(c->cost_key, key, sizeof key);

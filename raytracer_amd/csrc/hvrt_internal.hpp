@@ -70,6 +70,12 @@ struct RenderArgs {
     // k_render_split, 16 waves per tile (split_tiles[0, *n_split), both written by k_order_place; with order).
     const uint32_t* split_tiles;
     const uint32_t* n_split;
+    // k_render gives up on a tile whose rays are still inside long lists abort_clocks after they set out and
+    // appends it to abandoned[*n_abandoned++] (zeroed before the launch); a k_render_split launch behind it
+    // renders those tiles (split_tiles = abandoned, n_split = n_abandoned).
+    uint32_t* abandoned;
+    uint32_t* n_abandoned;
+    long long abort_clocks;
     uint32_t* tile_cost;
     unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
 };
@@ -102,7 +108,8 @@ hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* 
 int bounds_blocks(uint64_t n_points);
 
 // ---- launchers (hvrt_trace.hip) ----
-hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s);
+// abortable: the kernel may give up on over-long tiles (ra.abandoned); a launch_render_split over that list must follow
+hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
 hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s);
 // split_tiles <- the tiles for k_render_split; order <- the others: long tiles (cost > 2.5 x mean) first, the

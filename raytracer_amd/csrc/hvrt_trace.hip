@@ -101,11 +101,18 @@ struct TraceResult {
 // out the entries of every list (entry k of a chunk goes to slice k mod 64/RAYS); after the list, the slices'
 // candidates are reduced to the one the sequential loop would have kept -- the highest entry that hit (mode 0),
 // the smallest t, the lower entry on a tie (nearest-hit mode) -- so the result is the same bit for bit.
-template <bool COUNT, bool INLINE, bool NEAREST, int RAYS = 64>
-__device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d) {
+//
+// ABORT (k_render): a walk that is still inside a list of more than 32 entries when the clock passes `deadline`
+// gives up (tri = HVRT_ABORTED).  The clock is a scalar, so all lanes that are in such a list give up together;
+// the kernel then hands the whole tile to k_render_split.  Lists of up to 32 entries never look at the clock.
+constexpr uint32_t HVRT_ABORTED = 0xFFFFFFFEu;
+constexpr uint32_t COST_SPLIT_FLAG = 0x80000000u;   // top bit of a tile's cost word: the tile goes to k_render_split
+template <bool COUNT, bool INLINE, bool NEAREST, int RAYS = 64, bool ABORT = false>
+__device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d, long long deadline = 0) {
     const GridParams& g = sc.g;
     TraceResult r;
     r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
+    bool aborted = false;
 
     V3 st = o;
     if (NEAREST) {
@@ -234,6 +241,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
             static_assert(RAYS == 64 || RAYS == 16 || RAYS == 4, "slice masks are written for 1, 4 and 16 slices");
             const uint32_t slice_mask = RAYS == 64 ? 0xFFFFFFFFu : SLICE_BITS << ((threadIdx.x & 63u) / (uint32_t)RAYS);
             for (uint32_t c = 0; c < n; c += 32) {
+                if (ABORT && c != 0u && clock64() > deadline) { aborted = true; break; }
                 const uint32_t base = b0 + c;
                 uint32_t skip = 0;
                 if (face != NO_FACE) {
@@ -282,6 +290,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d)
                 }
             }
         }
+        if (ABORT && aborted) { r.tri = HVRT_ABORTED; break; }
         if (RAYS < 64) {
 #pragma unroll
             for (int m = RAYS; m < 64; m <<= 1) {
@@ -343,7 +352,9 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 
 // Persistent threads: every wave loops pulling 8x8 pixel tiles until the queue is empty; the
 // exit condition (tile >= n_tiles) is reached by every wave whatever the grid size.
-template <bool COUNT, bool INLINE, bool NEAREST>
+// ABORT: the variant for launches without tile history (see "gives up" below); launches with history run the
+// plain one -- the bookkeeping costs 4 % of a config 2 frame, and history already sends long tiles elsewhere.
+template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render(SceneDev sc, RenderArgs ra) {
     const int lane = threadIdx.x & 63;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
@@ -354,10 +365,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     const uint32_t n_queue = ra.order ? n_tiles - *ra.n_split : n_tiles;
     uint64_t tot_nv = 0, tot_nt = 0;
     unsigned long long wave_cost = 0;     // wave-uniform
+    uint32_t given_up = 0xFFFFFFFFu;      // wave-uniform: the tile the previous iteration gave up on (see below)
 
     for (;;) {
         uint32_t pulled = 0;
         if (lane == 0) {
+            if (ABORT && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
             pulled = atomicAdd(ra.tile_counter, 1u);
             if (pulled >= n_queue) {
                 pulled = 0xFFFFFFFFu;
@@ -377,6 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 }
             }
         }
+        given_up = 0xFFFFFFFFu;
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)pulled, 0);   // wave-uniform (an SGPR)
         if (tile >= n_tiles) break;
         const long long clk0 = clock64();
@@ -392,6 +406,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
         const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
         const V3 ver = { cf->vertical[0], cf->vertical[1], cf->vertical[2] };
+        // A tile whose rays are still inside long lists a millisecond after they set out is not finished here:
+        // the wave drops it (nothing of it is written or counted) and k_render_split, launched behind this
+        // kernel, renders it with 16 waves.  This is what bounds a launch that has no history of the scene yet;
+        // from the next launch on the recorded durations decide which tiles go to k_render_split from the start.
+        bool gave_up = false;
+        uint64_t tile_nv = 0, tile_nt = 0;
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
             V3 acc = { 0.0f, 0.0f, 0.0f };
             uint32_t hit0 = HVRT_MISS; float t0 = FLT_MAX;
@@ -403,27 +423,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const float v = ((float)y + jy) / (float)ra.height;
                 // generateRay, :361-364
                 const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
-                const TraceResult r = trace_ray<COUNT, INLINE, NEAREST>(sc, org, d);
+                const TraceResult r = trace_ray<COUNT, INLINE, NEAREST, 64, ABORT>(sc, org, d, clk0 + ra.abort_clocks * (s + 1));
+                if (ABORT && r.tri == HVRT_ABORTED) { gave_up = true; break; }
                 const V3 c = shade(sc, r, org, v);
                 if (ra.spp == 1) acc = c; else acc = add(acc, c);
                 if (s == 0) { hit0 = r.tri; t0 = r.t; }
-                if (COUNT) { tot_nv += r.nv; tot_nt += r.nt; }
+                if (COUNT) { tile_nv += r.nv; tile_nt += r.nt; }
             }
-            if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
-            const size_t p = ((size_t)fi * ra.slab_rows + lr) * ra.width + x;
-            if (ra.rgb) { ra.rgb[3 * p] = acc.x; ra.rgb[3 * p + 1] = acc.y; ra.rgb[3 * p + 2] = acc.z; }
-            if (ra.hit_id) ra.hit_id[p] = hit0;
-            if (ra.t) ra.t[p] = t0;
+            // lanes leave the sample loop together or not at all only per lane; the wave decides below, and a
+            // lane that finished its pixel holds its stores back until then
+            if (!ABORT || __ballot(gave_up) == 0ull) {
+                if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+                const size_t p = ((size_t)fi * ra.slab_rows + lr) * ra.width + x;
+                if (ra.rgb) { ra.rgb[3 * p] = acc.x; ra.rgb[3 * p + 1] = acc.y; ra.rgb[3 * p + 2] = acc.z; }
+                if (ra.hit_id) ra.hit_id[p] = hit0;
+                if (ra.t) ra.t[p] = t0;
+            }
         }
         // every lane is back here (the block above is structured); the clock is a scalar, so all lanes store
         // the same word -- no lane-0 branch at the loop's end, which keeps the loop's control flow simple
         {
+            const bool dropped = ABORT && __ballot(gave_up) != 0ull;
             const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
-            const uint32_t dc = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
-            ra.tile_cost[tile] = dc;
+            const uint32_t dc = dt > 0x00FFFFFFull ? 0x00FFFFFFu : (uint32_t)dt;
+            ra.tile_cost[tile] = dc;      // a dropped tile: k_render_split adds its quads' durations to this
             wave_cost += dc;
+            if (dropped) given_up = tile;                       // appended to the list by the next iteration
+            else if (COUNT) { tot_nv += tile_nv; tot_nt += tile_nt; }
         }
     }
+    if (ABORT && lane == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
     if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
     if (COUNT && ra.counters) {
         tot_nv = wave_sum64(tot_nv);
@@ -517,7 +546,6 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
 //   the others keep their natural order behind them -- neighbours in the queue stay neighbours in the image,
 //   which is what keeps the L1 / L2 hit rates (a full sort by cost was measured 7 % slower than no order).
 // Stable three-way partition: per-block counts of the first two classes, scan, placement.
-constexpr uint32_t COST_SPLIT_FLAG = 0x80000000u;
 
 __device__ __forceinline__ bool tile_wants_split(uint32_t c, unsigned long long sum, uint32_t slots) {
     return (c & COST_SPLIT_FLAG) || (unsigned long long)c * slots > sum;
@@ -670,7 +698,7 @@ uint64_t render_tile_count(int width, int local_rows, int n_frames) {
     return tiles_x * tiles_y * (uint64_t)n_frames;
 }
 
-hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s) {
+hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s) {
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0) return hipSuccess;
     uint64_t blocks = (n_tiles + 3) / 4;
@@ -678,15 +706,13 @@ hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, hi
     if (blocks > cap) blocks = cap;
     const bool il = sc.ref_rec != nullptr;
     const unsigned nb = (unsigned)blocks;
-#define HVRT_LAUNCH(C, I, N) k_render<C, I, N><<<nb, 256, 0, s>>>(sc, ra)
-    if (ra.nearest) {
-        if (ra.counters) { if (il) HVRT_LAUNCH(true, true, true); else HVRT_LAUNCH(true, false, true); }
-        else             { if (il) HVRT_LAUNCH(false, true, true); else HVRT_LAUNCH(false, false, true); }
-    } else {
-        if (ra.counters) { if (il) HVRT_LAUNCH(true, true, false); else HVRT_LAUNCH(true, false, false); }
-        else             { if (il) HVRT_LAUNCH(false, true, false); else HVRT_LAUNCH(false, false, false); }
-    }
+#define HVRT_LAUNCH3(C, I, N) do { if (abortable) k_render<C, I, N, true><<<nb, 256, 0, s>>>(sc, ra); \
+                                   else k_render<C, I, N, false><<<nb, 256, 0, s>>>(sc, ra); } while (0)
+#define HVRT_LAUNCH(C, I) do { if (ra.nearest) HVRT_LAUNCH3(C, I, true); else HVRT_LAUNCH3(C, I, false); } while (0)
+    if (ra.counters) { if (il) HVRT_LAUNCH(true, true); else HVRT_LAUNCH(true, false); }
+    else             { if (il) HVRT_LAUNCH(false, true); else HVRT_LAUNCH(false, false); }
 #undef HVRT_LAUNCH
+#undef HVRT_LAUNCH3
     return hipGetLastError();
 }
 

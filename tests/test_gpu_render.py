@@ -236,6 +236,30 @@ def test_split_tiles_change_nothing(ctx, mode):
         sc.set_mode(0)
 
 
+def test_tiles_given_up_on_are_rendered_by_the_split_kernel(monkeypatch):
+    """A launch without tile history runs the k_render variant that gives up on a tile whose rays are still inside
+    long lists after HVRT_TILE_ABORT_US (1 ms by default); k_render_split renders those tiles behind it.  With
+    the limit at 1 us every tile that meets a list of more than 32 entries takes that route: the frames (first
+    launch of each shape), hit ids, t and counters are still the oracle's, in both modes, with 1 and 3 samples."""
+    import raytracer_amd as ra
+    monkeypatch.setenv("HVRT_TILE_ABORT_US", "1")
+    own = ra.Context(0)
+    try:
+        tris = meshgen.skewed_statue(24, 120)
+        sc, mn, mx = setup_scene(own, tris, (32, 32, 32))
+        assert own.grid_info().max_list > 64
+        for mode in (0, 1):
+            own.set_mode(mode)
+            sc.set_mode(mode, mx)
+            for (W, H, spp) in ((328, 200, 1), (96, 64, 3)):
+                fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
+                exp = sc.render(fr, W, H, threads=16, spp=spp, seed=5)
+                for launch in range(2):          # the second one has history and splits from the start
+                    assert_frames_equal(own.render(fr, W, H, spp=spp, seed=5), exp)
+    finally:
+        own.close()
+
+
 def _quantise_ref(rgb):
     """ImageSaver.h:28-33: (uint8_t)clamp(c * 255.0f, 0.0f, 255.0f), truncating; NaN -> 0 (documented)."""
     v = rgb.astype(np.float32) * np.float32(255.0)
