@@ -207,15 +207,22 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                     }
                 }
             }
-            for (int i = 0; i < k; ++i) {
-                if (NEAREST && search && HVRT_NEAREST_DONE()) { done = true; search = false; }
-                if (search) {
+            // The k steps run without per-step branches: a lane that leaves the grid (or, in nearest-hit mode,
+            // is done) on the way keeps stepping -- its state is not used again -- and only remembers that it
+            // did (`alive`, `done` are sticky here).  Per-step exec-mask bookkeeping was two fifths of the
+            // kernel's scalar instructions, and the scalar unit is shared by the CU's four SIMDs.
+            if (search) {
+                bool going = true;
+                for (int i = 0; i < k; ++i) {
+                    if (NEAREST) { done = done || HVRT_NEAREST_DONE(); going = going && !done; }
                     HVRT_ADVANCE();
-                    search = alive;
+                    going = going && alive;
 #ifndef HVRT_DIAG
-                    if (COUNT && alive) ++r.nv;
+                    if (COUNT) r.nv += going ? 1u : 0u;
 #endif
                 }
+                alive = going || done;        // (a done lane leaves through `done`, not as a dead one)
+                search = going;
             }
         }
         if (NEAREST && done) break;
