@@ -157,7 +157,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
 #endif
 
     // cxy picks the x-or-y candidate, c2 compares that candidate with z: the nested ifs of :204-259
-#define HVRT_ADVANCE()                                                          \
+#define HVRT_STEP()                                                             \
     do {                                                                        \
         const bool cxy = tmx < tmy;                                             \
         const bool c2 = (cxy ? tmx : tmy) < tmz;                                \
@@ -168,6 +168,10 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
         rx -= stx ? 1 : 0; ry -= sty ? 1 : 0; rz -= c2 ? 0 : 1;                 \
         last = c2 ? (cxy ? fsx : fsy) : fsz;                                    \
         f += last;                                                              \
+    } while (0)
+#define HVRT_ADVANCE()                                                          \
+    do {                                                                        \
+        HVRT_STEP();                                                            \
         alive = (rx | ry | rz) >= 0;                                            \
     } while (0)
     // nearest-hit mode: is the kept hit at or before the exit of the current voxel (the tMax the next step takes)?
@@ -211,18 +215,26 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
             // is done) on the way keeps stepping -- its state is not used again -- and only remembers that it
             // did (`alive`, `done` are sticky here).  Per-step exec-mask bookkeeping was two fifths of the
             // kernel's scalar instructions, and the scalar unit is shared by the CU's four SIMDs.
+            // (The steps-left counters only ever decrease, so "still in the grid" needs one look after the k
+            // steps, not one per step, unless the steps are being counted.)
             if (search) {
-                bool going = true;
-                for (int i = 0; i < k; ++i) {
-                    if (NEAREST) { done = done || HVRT_NEAREST_DONE(); going = going && !done; }
-                    HVRT_ADVANCE();
-                    going = going && alive;
+                if (COUNT || NEAREST) {
+                    bool going = true;
+                    for (int i = 0; i < k; ++i) {
+                        if (NEAREST) { done = done || HVRT_NEAREST_DONE(); going = going && !done; }
+                        HVRT_ADVANCE();
+                        going = going && alive;
 #ifndef HVRT_DIAG
-                    if (COUNT) r.nv += going ? 1u : 0u;
+                        if (COUNT) r.nv += going ? 1u : 0u;
 #endif
+                    }
+                    alive = going || done;    // (a done lane leaves through `done`, not as a dead one)
+                    search = going;
+                } else {
+                    for (int i = 0; i < k; ++i) HVRT_STEP();
+                    alive = (rx | ry | rz) >= 0;
+                    search = alive;
                 }
-                alive = going || done;        // (a done lane leaves through `done`, not as a dead one)
-                search = going;
             }
         }
         if (NEAREST && done) break;
@@ -320,6 +332,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
 #endif
     }
 #undef HVRT_ADVANCE
+#undef HVRT_STEP
 #undef HVRT_NEAREST_DONE
 #undef HVRT_LOAD_VOXEL
     return r;

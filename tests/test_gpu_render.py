@@ -21,6 +21,19 @@ def setup_scene(ctx, tris, dims):
     return sc, mn, mx
 
 
+def render_both(ctx, *args, **kw):
+    """hvrt_render with and without the counters: two different kernel instantiations (the one without is the one
+    bench.py times; it checks "still in the grid" once per run of empty-space steps instead of per step).  Their
+    frames must be the same bits; the one with counters is returned for the comparison with the oracle."""
+    with_cnt = ctx.render(*args, **kw)
+    rgb, hit, t, none = ctx.render(*args, want_counters=False, **kw)
+    assert none is None
+    assert np.array_equal(hit, with_cnt[1]), "hit ids differ between the counting and the plain kernel"
+    assert np.array_equal(t.view(np.uint32), with_cnt[2].view(np.uint32))
+    assert np.array_equal(rgb.view(np.uint32), with_cnt[0].view(np.uint32))
+    return with_cnt
+
+
 def assert_frames_equal(got, exp):
     rgb, hit, t, cnt = got
     orgb, ohit, ot, ocnt = exp
@@ -58,7 +71,7 @@ def test_render_bit_exact(ctx, name, view):
     sc, mn, mx = setup_scene(ctx, tris, dims)
     pos, la, up, fov, asp = capi.default_camera(mn, mx, view)
     fr = capi.make_camera_frame(pos, la, up, fov, asp)
-    got = ctx.render(fr, W, H)
+    got = render_both(ctx, fr, W, H)
     exp = sc.render(fr, W, H, threads=8)
     assert_frames_equal(got, exp)
     if name.startswith("sphere") and view == "front":
@@ -76,7 +89,7 @@ def test_odd_sizes_and_tiny_images(ctx):
     pos, la, up, fov, asp = capi.default_camera(mn, mx)
     fr = capi.make_camera_frame(pos, la, up, fov, asp)
     for (W, H) in [(1, 1), (3, 5), (9, 7), (63, 65), (130, 17)]:
-        assert_frames_equal(ctx.render(fr, W, H), sc.render(fr, W, H, threads=1))
+        assert_frames_equal(render_both(ctx, fr, W, H), sc.render(fr, W, H, threads=1))
 
 
 def test_camera_inside_and_far_away(ctx):
@@ -87,7 +100,7 @@ def test_camera_inside_and_far_away(ctx):
                     ((40, 30, -20), (0, 0, 0)),               # oblique, start voxel clamped on 3 axes
                     ((0.5, 0.5, 0.5), (0.5, 0.5, 5))]:
         fr = capi.make_camera_frame(pos, la, (0, 1, 0), 60.0, 4 / 3)
-        assert_frames_equal(ctx.render(fr, 160, 120), sc.render(fr, 160, 120, threads=4))
+        assert_frames_equal(render_both(ctx, fr, 160, 120), sc.render(fr, 160, 120, threads=4))
 
 
 def test_trace_ray_batch(ctx):
@@ -142,11 +155,11 @@ def test_jittered_supersampling_extension(ctx):
     pos, la, up, fov, asp = capi.default_camera(mn, mx, aspect=16 / 9)
     fr = capi.make_camera_frame(pos, la, up, fov, asp)
     for spp, seed in [(4, 1), (16, 1234)]:
-        got = ctx.render(fr, 192, 108, spp=spp, seed=seed)
+        got = render_both(ctx, fr, 192, 108, spp=spp, seed=seed)
         exp = sc.render(fr, 192, 108, spp=spp, seed=seed, threads=8)
         assert_frames_equal(got, exp)
-    a = ctx.render(fr, 192, 108, spp=4, seed=1)[0]
-    b = ctx.render(fr, 192, 108, spp=4, seed=2)[0]
+    a = render_both(ctx, fr, 192, 108, spp=4, seed=1)[0]
+    b = render_both(ctx, fr, 192, 108, spp=4, seed=2)[0]
     assert not np.array_equal(a, b)
 
 
@@ -160,7 +173,7 @@ def test_row_tile_partition_reassembles_to_the_single_gpu_frame(ctx, n_parts, ti
     W, H = 200, 150
     pos, la, up, fov, asp = capi.default_camera(mn, mx)
     fr = capi.make_camera_frame(pos, la, up, fov, asp)
-    full_rgb, full_hit, full_t, _ = ctx.render(fr, W, H)
+    full_rgb, full_hit, full_t, _ = render_both(ctx, fr, W, H)
     slab = max(capi.part_rows(H, tile_rows, p, n_parts) for p in range(n_parts))
     dev = torch.device("cuda:0")
     parts_rgb = torch.zeros((n_parts, slab, W, 3), dtype=torch.float32, device=dev)
@@ -230,7 +243,7 @@ def test_split_tiles_change_nothing(ctx, mode):
             fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
             exp = sc.render(fr, W, H, threads=16, spp=spp, seed=5)
             for launch in range(4):
-                assert_frames_equal(ctx.render(fr, W, H, spp=spp, seed=5), exp)
+                assert_frames_equal(render_both(ctx, fr, W, H, spp=spp, seed=5), exp)
     finally:
         ctx.set_mode(0)
         sc.set_mode(0)
@@ -255,7 +268,7 @@ def test_tiles_given_up_on_are_rendered_by_the_split_kernel(monkeypatch):
                 fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
                 exp = sc.render(fr, W, H, threads=16, spp=spp, seed=5)
                 for launch in range(2):          # the second one has history and splits from the start
-                    assert_frames_equal(own.render(fr, W, H, spp=spp, seed=5), exp)
+                    assert_frames_equal(render_both(own, fr, W, H, spp=spp, seed=5), exp)
     finally:
         own.close()
 
@@ -276,7 +289,7 @@ def test_views_rgb8_is_the_float_frames_quantised_like_the_reference(ctx):
     rgb8, hit, cnt = ctx.render_views_rgb8(cams, W, H)
     tot = np.zeros(2, np.uint64)
     for f, cam in enumerate(cams):
-        rgb, h, t, c = ctx.render(cam, W, H)
+        rgb, h, t, c = render_both(ctx, cam, W, H)
         assert np.array_equal(rgb8[f], _quantise_ref(rgb)), f"view {f}"
         assert np.array_equal(hit[f], h)
         tot += c
@@ -312,17 +325,17 @@ def test_nearest_hit_mode_matches_the_oracle(ctx, name):
     tris, dims = NEAREST_SCENES[name]()
     sc, mn, mx = setup_scene(ctx, tris, dims)
     front = capi.make_camera_frame(*capi.default_camera(mn, mx))
-    ref_frame = ctx.render(front, 160, 120)
+    ref_frame = render_both(ctx, front, 160, 120)
     try:
         ctx.set_mode(1)
         sc.set_mode(1, mx)
         for view in ("front", "side", "top"):
             fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view))
-            assert_frames_equal(ctx.render(fr, 160, 120), sc.render(fr, 160, 120, threads=4))
-            assert_frames_equal(ctx.render(fr, 160, 120), sc.render(fr, 160, 120, threads=4))   # re-ordered launch
+            assert_frames_equal(render_both(ctx, fr, 160, 120), sc.render(fr, 160, 120, threads=4))
+            assert_frames_equal(render_both(ctx, fr, 160, 120), sc.render(fr, 160, 120, threads=4))   # re-ordered launch
         c = (np.asarray(mn) + np.asarray(mx)) / 2
         inside = capi.make_camera_frame(tuple(c), tuple(c + np.array([0.3, 0.2, 1.0], np.float32)), (0, 1, 0), 80.0, 4 / 3)
-        assert_frames_equal(ctx.render(inside, 120, 90, spp=2, seed=3), sc.render(inside, 120, 90, spp=2, seed=3, threads=4))
+        assert_frames_equal(render_both(ctx, inside, 120, 90, spp=2, seed=3), sc.render(inside, 120, 90, spp=2, seed=3, threads=4))
         rng = np.random.default_rng(11)
         n = 3000
         o = (c + rng.uniform(-2.5, 2.5, (n, 3)) * (np.asarray(mx) - np.asarray(mn))).astype(np.float32)
@@ -339,7 +352,7 @@ def test_nearest_hit_mode_matches_the_oracle(ctx, name):
     finally:
         ctx.set_mode(0)
         sc.set_mode(0)
-    assert_frames_equal(ctx.render(front, 160, 120), ref_frame)
+    assert_frames_equal(render_both(ctx, front, 160, 120), ref_frame)
     assert_frames_equal(ref_frame, sc.render(front, 160, 120, threads=4))
     with pytest.raises(capi.HvrtError):
         ctx.set_mode(2)
@@ -349,7 +362,7 @@ def test_render_requires_a_scene(ctx):
     ctx.set_mesh(meshgen.box())      # drops any grid
     fr = capi.make_camera_frame((0, 0, -5), (0, 0, 0), (0, 1, 0), 60.0, 4 / 3)
     with pytest.raises(capi.HvrtError):
-        ctx.render(fr, 16, 16)
+        render_both(ctx, fr, 16, 16)
 
 
 def test_config2_full_size_render_rows(ctx):
@@ -365,7 +378,7 @@ def test_config2_full_size_render_rows(ctx):
     W, H = 3840, 2160
     pos, la, up, fov, asp = capi.default_camera(mn, mx, aspect=W / H)
     fr = capi.make_camera_frame(pos, la, up, fov, asp)
-    rgb, hit, t, cnt = ctx.render(fr, W, H)
+    rgb, hit, t, cnt = render_both(ctx, fr, W, H)
     rows = list(range(0, H, 8))
     ohit = np.zeros((len(rows), W), np.uint32)
     ot = np.zeros((len(rows), W), np.float32)
@@ -401,7 +414,7 @@ def _rows_against_oracle(ctx, tris, g, W, H, rows, spp=1, seed=0, launches=1):
     sc = oracle.OracleScene(tris, g, g, g, mn, vs, off, idx)
     fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
     for _ in range(launches):            # later launches pull their tiles in the order the first one measured
-        rgb, hit, t, cnt = ctx.render(fr, W, H, spp=spp, seed=seed)
+        rgb, hit, t, cnt = render_both(ctx, fr, W, H, spp=spp, seed=seed)
     ohit = np.zeros((len(rows), W), np.uint32)
     ot = np.zeros((len(rows), W), np.float32)
     orgb = np.zeros((len(rows), W, 3), np.float32)
@@ -448,7 +461,7 @@ def test_render_from_an_ingested_cpu_grid(ctx, name):
     for view in ("front", "top"):
         pos, la, up, fov, asp = capi.default_camera(mn, mx, view)
         fr = capi.make_camera_frame(pos, la, up, fov, asp)
-        assert_frames_equal(ctx.render(fr, W, H), sc.render(fr, W, H, threads=8))
+        assert_frames_equal(render_both(ctx, fr, W, H), sc.render(fr, W, H, threads=8))
 
 
 def test_ingested_grid_with_unsorted_or_foreign_lists(ctx):
@@ -472,7 +485,7 @@ def test_ingested_grid_with_unsorted_or_foreign_lists(ctx):
     ctx.set_grid_csr(20, 20, 20, mn, mx, vs, noff, nidx)
     pos, la, up, fov, asp = capi.default_camera(mn, mx)
     fr = capi.make_camera_frame(pos, la, up, fov, asp)
-    assert_frames_equal(ctx.render(fr, 200, 150), sc2.render(fr, 200, 150, threads=8))
+    assert_frames_equal(render_both(ctx, fr, 200, 150), sc2.render(fr, 200, 150, threads=8))
     bad = nidx.copy()
     bad[5] = tris.shape[0] + 7
     with pytest.raises(capi.HvrtError):
