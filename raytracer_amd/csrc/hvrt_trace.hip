@@ -48,7 +48,11 @@ __device__ __forceinline__ V3 normalize(V3 v) {
 // test is rejected early only when u~ < -1e-3, u~ > 1.001, v~ < -1e-3 or u~ + v~ > 1.002 -- each of which
 // implies the reference's own rejection.  Everything else (including every NaN / inf case, which fails the
 // early compares) takes the exact path below, so hit / miss and t are bit-identical.
-__device__ __forceinline__ bool ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float& t_out) {
+// on_hit(t) runs where the hit is established (nested ifs, not early returns + a flag tested by the caller): a
+// rejected test then skips straight to the loop's end through one exec-mask restore -- every mask operation in
+// this loop is an instruction of the CU's one scalar unit.
+template <class OnHit>
+__device__ __forceinline__ void ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, OnHit on_hit) {
     V3 p = cross(d, e2);
     float det = dot(e1, p);
     V3 s = sub(o, v0);
@@ -57,19 +61,22 @@ __device__ __forceinline__ bool ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, fl
     const float ua = su * r;
     // one exit for "parallel" (the reference's first test) and "u far outside": no branch sits between the
     // record's loads, so they are issued together instead of v0 waiting for the determinant
-    if ((det > -EPS && det < EPS) | (ua < -1e-3f) | (ua > 1.001f)) return false;
-    V3 q = cross(s, e1);
-    float sv = dot(d, q);
-    const float va = sv * r;
-    if (va < -1e-3f || ua + va > 1.002f) return false;
-    float inv = 1.0f / det;   // == (float)(1.0 / (double)det): double rounding is innocuous for 53 >= 2*24+2
-    float u = inv * su;
-    if ((u < 0.0f && fabsf(u) > EPS) || (u > 1.0f && fabsf(u - 1.0f) > EPS)) return false;
-    float v = inv * sv;
-    if ((v < 0.0f && fabsf(v) > EPS) || (u + v > 1.0f && fabsf(u + v - 1.0f) > EPS)) return false;
-    float t = inv * dot(e2, q);
-    t_out = t;
-    return t > EPS;
+    if (!((det > -EPS && det < EPS) | (ua < -1e-3f) | (ua > 1.001f))) {
+        V3 q = cross(s, e1);
+        float sv = dot(d, q);
+        const float va = sv * r;
+        if (!(va < -1e-3f || ua + va > 1.002f)) {
+            float inv = 1.0f / det;   // == (float)(1.0 / (double)det): double rounding is innocuous for 53 >= 2*24+2
+            float u = inv * su;
+            if (!((u < 0.0f && fabsf(u) > EPS) || (u > 1.0f && fabsf(u - 1.0f) > EPS))) {
+                float v = inv * sv;
+                if (!((v < 0.0f && fabsf(v) > EPS) || (u + v > 1.0f && fabsf(u + v - 1.0f) > EPS))) {
+                    float t = inv * dot(e2, q);
+                    if (t > EPS) on_hit(t);
+                }
+            }
+        }
+    }
 }
 
 struct TraceResult {
@@ -246,7 +253,6 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                             : (last == fsx && g.nx > 1) ? facex
                             : (last == fsy && g.ny > 1) ? facey : facez;
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
-        bool found = false;
         uint32_t bkey = 0;   // RAYS < 64: 1 + list position of this slice's candidate, 0 = none from this list
         {
             // Entries that are also in the list of the voxel the ray just left were tested there one step
@@ -274,7 +280,6 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                     const uint32_t k = (uint32_t)__builtin_ctz(todo);
                     todo &= todo - 1;
                     const uint32_t j = base + k;
-                    float t;
 #ifdef HVRT_DIAG   // diagnostic build only: nt = tests executed, nv = 64 x wave-level test iterations
 #if HVRT_DIAG == 2   // nt = 64 x wave-level iterations in which every active lane tests the SAME entry
                     if (COUNT) {
@@ -291,20 +296,22 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                         // 36 of the record's 48 bytes; the triangle id (10th dword) is fetched only on a hit
                         const float4 c0 = rec[0], c1 = rec[1];
                         const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
-                        if (ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, t) &&
-                            (!NEAREST || t < r.t)) {
-                            r.tri = __float_as_uint(reinterpret_cast<const float*>(rec + 2)[1]); r.t = t; found = true;
-                            if (RAYS < 64) bkey = c + k + 1u;
-                        }
+                        ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, [&](float t) {
+                            if (!NEAREST || t < r.t) {
+                                r.tri = __float_as_uint(reinterpret_cast<const float*>(rec + 2)[1]); r.t = t;
+                                if (RAYS < 64) bkey = c + k + 1u;
+                            }
+                        });
                     } else {
                         const uint32_t ti = sc.indices[j];
                         const float4 r0 = sc.tri_rec[3ull * ti], r1 = sc.tri_rec[3ull * ti + 1];
                         const float e2z = reinterpret_cast<const float*>(sc.tri_rec + 3ull * ti + 2)[0];
-                        if (ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, e2z }, o, d, t) &&
-                            (!NEAREST || t < r.t)) {
-                            r.tri = ti; r.t = t; found = true;
-                            if (RAYS < 64) bkey = c + k + 1u;
-                        }
+                        ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, e2z }, o, d, [&](float t) {
+                            if (!NEAREST || t < r.t) {
+                                r.tri = ti; r.t = t;
+                                if (RAYS < 64) bkey = c + k + 1u;
+                            }
+                        });
                     }
                 }
             }
@@ -318,13 +325,12 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                 const bool take = NEAREST ? (ot < r.t || (ot == r.t && ok < bkey)) : ok > bkey;
                 if (take) { bkey = ok; r.tri = otri; r.t = ot; }
             }
-            if (!NEAREST) found = bkey != 0u;
         }
 #ifndef HVRT_DIAG
         if (COUNT) r.nt += b1 - b0;
 #endif
         if (NEAREST) { if (HVRT_NEAREST_DONE()) break; }
-        else if (found) break;   // :326-329
+        else if (r.tri != HVRT_MISS) break;   // :326-329 (no flag to carry through the loops: tri is MISS until a hit)
         HVRT_ADVANCE();
         if (!alive) break;
 #ifndef HVRT_DIAG
