@@ -79,6 +79,9 @@ __device__ __forceinline__ void ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, On
     }
 }
 
+// the mask of lanes for which b holds, straight from the compare (HIP's __ballot goes through an integer)
+__device__ __forceinline__ unsigned long long any_lane(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
 struct TraceResult {
     uint32_t tri;   // HVRT_MISS when nothing was hit
     float t;
@@ -158,7 +161,6 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
     const uint32_t facex = px ? 0u : 1u, facey = py ? 2u : 3u, facez = pz ? 4u : 5u;
     uint32_t last = 0;   // 0 = no step taken yet (an increment is never 0)
     uint32_t b0, b1;
-    bool alive = true;
 #ifndef HVRT_DIAG
     if (COUNT) r.nv = 1;
 #endif
@@ -176,11 +178,8 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
         last = c2 ? (cxy ? fsx : fsy) : fsz;                                    \
         f += last;                                                              \
     } while (0)
-#define HVRT_ADVANCE()                                                          \
-    do {                                                                        \
-        HVRT_STEP();                                                            \
-        alive = (rx | ry | rz) >= 0;                                            \
-    } while (0)
+    // the steps-left counters only ever decrease: once one is negative the ray has left the grid for good
+#define HVRT_IN_GRID() ((rx | ry | rz) >= 0)
     // nearest-hit mode: is the kept hit at or before the exit of the current voxel (the tMax the next step takes)?
 #define HVRT_NEAREST_DONE()                                                     \
     (r.tri != HVRT_MISS && r.t <= (((tmx < tmy ? tmx : tmy) < tmz) ? (tmx < tmy ? tmx : tmy) : tmz))
@@ -199,28 +198,28 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
         // k <= min(dist) steps (k a power of two, found with ballots: one compare near a surface, where
         // k = 1, a few in open space) -- because a vector load costs the L1 a slot per quad of lanes, however
         // few of them want it.
-        bool search = alive;
+        bool search = true;      // every lane that gets here is in the grid
         bool done = false;
         for (;;) {
             uint32_t dd = 255u;
             if (search) dd = dist[f];
             search = search && dd != 0u;
-            if (__ballot(search) == 0ull) break;
+            if (any_lane(search) == 0ull) break;
             const uint32_t ds = search ? dd : 255u;
             int k = 1;
-            if (__ballot(ds < 2u) == 0ull) {
+            if (any_lane(ds < 2u) == 0ull) {
                 k = 2;
-                if (__ballot(ds < 4u) == 0ull) {
+                if (any_lane(ds < 4u) == 0ull) {
                     k = 4;
-                    if (__ballot(ds < 8u) == 0ull) {
+                    if (any_lane(ds < 8u) == 0ull) {
                         k = 8;
-                        if (__ballot(ds < 16u) == 0ull) k = __ballot(ds < 32u) == 0ull ? 32 : 16;
+                        if (any_lane(ds < 16u) == 0ull) k = any_lane(ds < 32u) == 0ull ? 32 : 16;
                     }
                 }
             }
             // The k steps run without per-step branches: a lane that leaves the grid (or, in nearest-hit mode,
             // is done) on the way keeps stepping -- its state is not used again -- and only remembers that it
-            // did (`alive`, `done` are sticky here).  Per-step exec-mask bookkeeping was two fifths of the
+            // did (the counters and `done` are sticky).  Per-step exec-mask bookkeeping was two fifths of the
             // kernel's scalar instructions, and the scalar unit is shared by the CU's four SIMDs.
             // (The steps-left counters only ever decrease, so "still in the grid" needs one look after the k
             // steps, not one per step, unless the steps are being counted.)
@@ -229,23 +228,21 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                     bool going = true;
                     for (int i = 0; i < k; ++i) {
                         if (NEAREST) { done = done || HVRT_NEAREST_DONE(); going = going && !done; }
-                        HVRT_ADVANCE();
-                        going = going && alive;
+                        HVRT_STEP();
+                        going = going && HVRT_IN_GRID();
 #ifndef HVRT_DIAG
                         if (COUNT) r.nv += going ? 1u : 0u;
 #endif
                     }
-                    alive = going || done;    // (a done lane leaves through `done`, not as a dead one)
                     search = going;
                 } else {
                     for (int i = 0; i < k; ++i) HVRT_STEP();
-                    alive = (rx | ry | rz) >= 0;
-                    search = alive;
+                    search = HVRT_IN_GRID();
                 }
             }
         }
         if (NEAREST && done) break;
-        if (!alive) break;
+        if (!HVRT_IN_GRID()) break;
         HVRT_LOAD_VOXEL();
         // a surviving x step implies nx > 1 (it would have left a 1-wide grid), so fsx, fsy, fsz are told
         // apart by testing the axes in this order with their extent
@@ -331,13 +328,13 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
 #endif
         if (NEAREST) { if (HVRT_NEAREST_DONE()) break; }
         else if (r.tri != HVRT_MISS) break;   // :326-329 (no flag to carry through the loops: tri is MISS until a hit)
-        HVRT_ADVANCE();
-        if (!alive) break;
+        HVRT_STEP();
+        if (!HVRT_IN_GRID()) break;
 #ifndef HVRT_DIAG
         if (COUNT) ++r.nv;
 #endif
     }
-#undef HVRT_ADVANCE
+#undef HVRT_IN_GRID
 #undef HVRT_STEP
 #undef HVRT_NEAREST_DONE
 #undef HVRT_LOAD_VOXEL
