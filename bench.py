@@ -206,7 +206,7 @@ def main():
                                "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
                                "note": "algorithmic (requested) bytes 8V+40T+20 per ray; >1 means the bytes are served "
                                        "from cache or never requested; the binding resources are per-CU, see binding",
-                               "binding": {k: prof[k] for k in ("td_busy_frac", "ta_busy_frac", "valu_issue_frac", "l2_hit_rate",
+                               "binding": {k: prof[k] for k in ("valu_issue_frac", "salu_issue_frac", "td_busy_frac", "ta_busy_frac", "l2_hit_rate",
                                                                 "busy_source") if k in prof}}
             nvox = g ** 3
             b_build = 72.0 * info.n_triangles + 12.0 * nvox + 20.0 * info.n_refs
