@@ -147,7 +147,10 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
     float tmz = ((g.mnz + (float)(pz ? iz + 1 : iz) * g.vsz) - o.z) / d.z;
     int rx = px ? g.nx - 1 - ix : ix;      // steps left on each axis before the ray leaves the grid
     int ry = py ? g.ny - 1 - iy : iy;
-    int rz = pz ? g.nz - 1 - iz : iz;
+    // z has no counter of its own: z steps = all steps - x steps - y steps, so its steps-left value is
+    // zsum - tot - rx - ry (tot = steps taken so far; a run of k steps adds k once, not 1 k times)
+    const int zsum = (pz ? g.nz - 1 - iz : iz) + rx + ry;
+    int tot = 0;
     const uint32_t plane = (uint32_t)g.nx * (uint32_t)g.ny;
     const uint32_t fsx = px ? 1u : 0xFFFFFFFFu;
     const uint32_t fsy = py ? (uint32_t)g.nx : 0u - (uint32_t)g.nx;
@@ -174,12 +177,12 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
         tmx = stx ? tmx + tdx : tmx;                                            \
         tmy = sty ? tmy + tdy : tmy;                                            \
         tmz = c2 ? tmz : tmz + tdz;                                             \
-        rx -= stx ? 1 : 0; ry -= sty ? 1 : 0; rz -= c2 ? 0 : 1;                 \
+        rx -= stx ? 1 : 0; ry -= sty ? 1 : 0;                                   \
         last = c2 ? (cxy ? fsx : fsy) : fsz;                                    \
         f += last;                                                              \
     } while (0)
     // the steps-left counters only ever decrease: once one is negative the ray has left the grid for good
-#define HVRT_IN_GRID() ((rx | ry | rz) >= 0)
+#define HVRT_IN_GRID() ((rx | ry | (zsum - tot - rx - ry)) >= 0)
     // nearest-hit mode: is the kept hit at or before the exit of the current voxel (the tMax the next step takes)?
 #define HVRT_NEAREST_DONE()                                                     \
     (r.tri != HVRT_MISS && r.t <= (((tmx < tmy ? tmx : tmy) < tmz) ? (tmx < tmy ? tmx : tmy) : tmz))
@@ -229,6 +232,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                     for (int i = 0; i < k; ++i) {
                         if (NEAREST) { done = done || HVRT_NEAREST_DONE(); going = going && !done; }
                         HVRT_STEP();
+                        ++tot;
                         going = going && HVRT_IN_GRID();
 #ifndef HVRT_DIAG
                         if (COUNT) r.nv += going ? 1u : 0u;
@@ -237,6 +241,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                     search = going;
                 } else {
                     for (int i = 0; i < k; ++i) HVRT_STEP();
+                    tot += k;
                     search = HVRT_IN_GRID();
                 }
             }
@@ -329,6 +334,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
         if (NEAREST) { if (HVRT_NEAREST_DONE()) break; }
         else if (r.tri != HVRT_MISS) break;   // :326-329 (no flag to carry through the loops: tri is MISS until a hit)
         HVRT_STEP();
+        ++tot;
         if (!HVRT_IN_GRID()) break;
 #ifndef HVRT_DIAG
         if (COUNT) ++r.nv;
