@@ -160,8 +160,10 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
     const uint32_t* __restrict__ offs = sc.offsets;
     // face through which the current voxel was entered: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z, 5 +z neighbour
     // (kept as the last step's index increment; decoded only when a voxel has a list to test)
-    constexpr uint32_t NO_FACE = 6;
-    const uint32_t facex = px ? 0u : 1u, facey = py ? 2u : 3u, facez = pz ? 4u : 5u;
+    // (kept as the word offset of that face's bit array, so that no multiply sits in the loop:
+    // 6 * face_words < 2^30 because there are fewer than 2^32 entries)
+    const uint32_t fw = (uint32_t)sc.face_words;
+    const uint32_t facex = (px ? 0u : 1u) * fw, facey = (py ? 2u : 3u) * fw, facez = (pz ? 4u : 5u) * fw;
     uint32_t last = 0;   // 0 = no step taken yet (an increment is never 0)
     uint32_t b0, b1;
 #ifndef HVRT_DIAG
@@ -251,9 +253,8 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
         HVRT_LOAD_VOXEL();
         // a surviving x step implies nx > 1 (it would have left a 1-wide grid), so fsx, fsy, fsz are told
         // apart by testing the axes in this order with their extent
-        const uint32_t face = last == 0u ? NO_FACE
-                            : (last == fsx && g.nx > 1) ? facex
-                            : (last == fsy && g.ny > 1) ? facey : facez;
+        const bool entered = last != 0u;          // false: the ray's first voxel, nothing was tested before
+        const uint32_t face = (last == fsx && g.nx > 1) ? facex : (last == fsy && g.ny > 1) ? facey : facez;
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         uint32_t bkey = 0;   // RAYS < 64: 1 + list position of this slice's candidate, 0 = none from this list
         {
@@ -271,8 +272,8 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
                 if (ABORT && c != 0u && clock64() > deadline) { aborted = true; break; }
                 const uint32_t base = b0 + c;
                 uint32_t skip = 0;
-                if (face != NO_FACE) {
-                    const uint32_t* __restrict__ fb = sc.face_bits + (uint64_t)face * sc.face_words + (base >> 5);
+                if (entered) {
+                    const uint32_t* __restrict__ fb = sc.face_bits + (face + (base >> 5));
                     skip = __builtin_amdgcn_alignbit(fb[1], fb[0], base & 31u);
                 }
                 const uint32_t left = n - c;
