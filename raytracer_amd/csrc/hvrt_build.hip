@@ -866,15 +866,18 @@ hipError_t launch_distance_field(const uint32_t* offsets, const GridParams& g, u
         if (nx % 4 == 0 && nx <= 16384) k_dist_x4<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
         else k_dist_x<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
     }
-    // four lines per lane where line starts and strides are multiples of 4 (dist itself is 256-B aligned)
+    // four lines per lane where line starts and strides are multiples of 4 (dist itself is 256-B aligned) -- but
+    // only when that still leaves every SIMD a few waves: a sweep is a serial chain per lane, and at 256^3 four
+    // lines per lane are 256 waves for 1024 SIMDs
+    constexpr uint64_t SWEEP_WIDE_MIN = 4 * 64 * 1024;
     if (ny > 1) {
         const uint64_t lines = nx * nz;
-        if (nx % 4 == 0) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, nx, nx * ny, nx, (uint32_t)ny);
+        if (nx % 4 == 0 && lines >= SWEEP_WIDE_MIN) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, nx, nx * ny, nx, (uint32_t)ny);
         else k_dist_sweep<1><<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, nx, nx * ny, nx, (uint32_t)ny);
     }
     if (nz > 1) {
         const uint64_t lines = nx * ny;
-        if (lines % 4 == 0) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, lines, 0, lines, (uint32_t)nz);
+        if (lines % 4 == 0 && lines >= SWEEP_WIDE_MIN) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, lines, 0, lines, (uint32_t)nz);
         else k_dist_sweep<1><<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, lines, 0, lines, (uint32_t)nz);
     }
     return hipGetLastError();
