@@ -380,6 +380,47 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     return v;
 }
 
+// What both render kernels do for one pixel: the spp samples of pixel (x, y) of frame `cf` -- renderPixel
+// (OctreeLikeRayTracer.cpp:73-74; pixel corner, jitter is 0 at spp 1), generateRay (:361-364), the traversal and
+// the shading.  Returns false when ABORT is set and a walk gave up (nothing of the pixel is valid then).
+struct PixelResult {
+    V3 rgb;              // mean of the samples
+    uint32_t hit; float t;   // sample 0's
+    uint64_t nv, nt;     // counters over all samples
+};
+template <bool COUNT, bool INLINE, bool NEAREST, int RAYS, bool ABORT>
+__device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArgs& ra, const hvrt_camera_frame* __restrict__ cf,
+                                             int x, int y, long long clk0, PixelResult& out) {
+    const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };          // wave-uniform: scalar loads
+    const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
+    const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
+    const V3 ver = { cf->vertical[0], cf->vertical[1], cf->vertical[2] };
+    V3 acc = { 0.0f, 0.0f, 0.0f };
+    out.hit = HVRT_MISS; out.t = FLT_MAX; out.nv = 0; out.nt = 0;
+    for (int s = 0; s < ra.spp; ++s) {
+        float jx = 0.0f, jy = 0.0f;
+        if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
+        const float u = ((float)x + jx) / (float)ra.width;
+        const float v = ((float)y + jy) / (float)ra.height;
+        const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
+        const TraceResult r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, clk0 + ra.abort_clocks * (s + 1));
+        if (ABORT && r.tri == HVRT_ABORTED) return false;
+        const V3 c = shade(sc, r, org, v);
+        if (ra.spp == 1) acc = c; else acc = add(acc, c);
+        if (s == 0) { out.hit = r.tri; out.t = r.t; }
+        if (COUNT) { out.nv += r.nv; out.nt += r.nt; }
+    }
+    if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+    out.rgb = acc;
+    return true;
+}
+__device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame, int local_row, int x, const PixelResult& px) {
+    const size_t p = ((size_t)frame * ra.slab_rows + local_row) * ra.width + x;
+    if (ra.rgb) { ra.rgb[3 * p] = px.rgb.x; ra.rgb[3 * p + 1] = px.rgb.y; ra.rgb[3 * p + 2] = px.rgb.z; }
+    if (ra.hit_id) ra.hit_id[p] = px.hit;
+    if (ra.t) ra.t[p] = px.t;
+}
+
 // Persistent threads: every wave loops pulling 8x8 pixel tiles until the queue is empty; the
 // exit condition (tile >= n_tiles) is reached by every wave whatever the grid size.
 // ABORT: the variant for launches without tile history (see "gives up" below); launches with history run the
@@ -431,55 +472,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         // local row -> global row: tile k of the image belongs to part k % n_parts
         const int kl = lr / ra.tile_rows;
         const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
-        const hvrt_camera_frame* __restrict__ cf = ra.frames + fi;          // wave-uniform: scalar loads
-        const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };
-        const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
-        const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
-        const V3 ver = { cf->vertical[0], cf->vertical[1], cf->vertical[2] };
         // A tile whose rays are still inside long lists a millisecond after they set out is not finished here:
         // the wave drops it (nothing of it is written or counted) and k_render_split, launched behind this
         // kernel, renders it with 16 waves.  This is what bounds a launch that has no history of the scene yet;
         // from the next launch on the recorded durations decide which tiles go to k_render_split from the start.
         bool gave_up = false;
-        uint64_t tile_nv = 0, tile_nt = 0;
+        PixelResult px;
+        px.nv = px.nt = 0;
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
-            V3 acc = { 0.0f, 0.0f, 0.0f };
-            uint32_t hit0 = HVRT_MISS; float t0 = FLT_MAX;
-            for (int s = 0; s < ra.spp; ++s) {
-                float jx = 0.0f, jy = 0.0f;
-                if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
-                // renderPixel, :73-74 (pixel corner; jitter is 0 at spp 1)
-                const float u = ((float)x + jx) / (float)ra.width;
-                const float v = ((float)y + jy) / (float)ra.height;
-                // generateRay, :361-364
-                const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
-                const TraceResult r = trace_ray<COUNT, INLINE, NEAREST, 64, ABORT>(sc, org, d, clk0 + ra.abort_clocks * (s + 1));
-                if (ABORT && r.tri == HVRT_ABORTED) { gave_up = true; break; }
-                const V3 c = shade(sc, r, org, v);
-                if (ra.spp == 1) acc = c; else acc = add(acc, c);
-                if (s == 0) { hit0 = r.tri; t0 = r.t; }
-                if (COUNT) { tile_nv += r.nv; tile_nt += r.nt; }
-            }
-            // lanes leave the sample loop together or not at all only per lane; the wave decides below, and a
-            // lane that finished its pixel holds its stores back until then
-            if (!ABORT || __ballot(gave_up) == 0ull) {
-                if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
-                const size_t p = ((size_t)fi * ra.slab_rows + lr) * ra.width + x;
-                if (ra.rgb) { ra.rgb[3 * p] = acc.x; ra.rgb[3 * p + 1] = acc.y; ra.rgb[3 * p + 2] = acc.z; }
-                if (ra.hit_id) ra.hit_id[p] = hit0;
-                if (ra.t) ra.t[p] = t0;
-            }
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, clk0, px);
+            // the wave decides; a lane that finished its pixel holds its stores back until then
+            if (!ABORT || any_lane(gave_up) == 0ull) store_pixel(ra, fi, lr, x, px);
         }
         // every lane is back here (the block above is structured); the clock is a scalar, so all lanes store
         // the same word -- no lane-0 branch at the loop's end, which keeps the loop's control flow simple
         {
-            const bool dropped = ABORT && __ballot(gave_up) != 0ull;
+            const bool dropped = ABORT && any_lane(gave_up) != 0ull;
             const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
             const uint32_t dc = dt > 0x00FFFFFFull ? 0x00FFFFFFu : (uint32_t)dt;
             ra.tile_cost[tile] = dc;      // a dropped tile: k_render_split adds its quads' durations to this
             wave_cost += dc;
             if (dropped) given_up = tile;                       // appended to the list by the next iteration
-            else if (COUNT) { tot_nv += tile_nv; tot_nt += tile_nt; }
+            else if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
         }
     }
     if (ABORT && lane == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
@@ -521,32 +535,12 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
         const int lr = (int)(ty * 8u) + (int)(quad >> 2) * 2 + (ray >> 1);
         const int kl = lr / ra.tile_rows;
         const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
-        const hvrt_camera_frame* __restrict__ cf = ra.frames + fi;
-        const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };
-        const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
-        const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
-        const V3 ver = { cf->vertical[0], cf->vertical[1], cf->vertical[2] };
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
-            V3 acc = { 0.0f, 0.0f, 0.0f };
-            uint32_t hit0 = HVRT_MISS; float t0 = FLT_MAX;
-            for (int s = 0; s < ra.spp; ++s) {
-                float jx = 0.0f, jy = 0.0f;
-                if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
-                const float u = ((float)x + jx) / (float)ra.width;
-                const float v = ((float)y + jy) / (float)ra.height;
-                const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
-                const TraceResult r = trace_ray<COUNT, INLINE, NEAREST, 4>(sc, org, d);
-                const V3 c = shade(sc, r, org, v);
-                if (ra.spp == 1) acc = c; else acc = add(acc, c);
-                if (s == 0) { hit0 = r.tri; t0 = r.t; }
-                if (COUNT && slice == 0) { tot_nv += r.nv; tot_nt += r.nt; }
-            }
-            if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+            PixelResult px;
+            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, x, y, clk0, px);
             if (slice == 0) {
-                const size_t p = ((size_t)fi * ra.slab_rows + lr) * ra.width + x;
-                if (ra.rgb) { ra.rgb[3 * p] = acc.x; ra.rgb[3 * p + 1] = acc.y; ra.rgb[3 * p + 2] = acc.z; }
-                if (ra.hit_id) ra.hit_id[p] = hit0;
-                if (ra.t) ra.t[p] = t0;
+                store_pixel(ra, fi, lr, x, px);
+                if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
             }
         }
         const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
