@@ -347,7 +347,16 @@ __global__ __launch_bounds__(256) void k_rank_sort(const uint32_t* __restrict__ 
     const uint32_t len = b1 - b0;
     if (len <= SORT_SMALL) {
         uint32_t rank = 0;
-        for (uint32_t q = b0; q < b1; ++q) rank += unsorted[q] < key;
+        // (eight independent loads in flight: the loop is a chain of L1 / L2 latencies otherwise)
+        uint32_t q = b0;
+        for (; q + 8 <= b1; q += 8) {
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) w[k] = unsorted[q + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) rank += w[k] < key;
+        }
+        for (; q < b1; ++q) rank += unsorted[q] < key;
         sorted[b0 + rank] = key;
     } else {
         sorted[j] = key;
