@@ -56,6 +56,8 @@ struct hvrt_ctx {
     // build scratch
     uint32_t* ranges = nullptr;   uint64_t ranges_capacity = 0;
     uint64_t* block_sums = nullptr; uint64_t block_sums_capacity = 0;
+    uint32_t* occ_bits = nullptr; uint64_t occ_bits_capacity = 0;   // one bit per voxel, left by the scan for the distance field
+    bool occ_bits_valid = false;
     uint64_t* stats = nullptr;     // 8 x u64
     uint32_t* long_queue = nullptr; uint64_t long_queue_capacity = 0;
     uint32_t* fill_scratch = nullptr; uint64_t fill_scratch_capacity = 0;  // unsorted ids | voxel of each entry
@@ -229,7 +231,7 @@ int fork_distance_field(hvrt_ctx* c, hipStream_t s) {
     if (int r = ensure<uint8_t>(c, c->dist, c->dist_capacity, c->g.nvox + 64)) return r;
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
     HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    HIP_TRY(c, launch_distance_field(offsets_of(c), c->g, c->dist, c->aux_stream));
+    HIP_TRY(c, launch_distance_field(offsets_of(c), c->occ_bits_valid ? c->occ_bits : nullptr, c->g, c->dist, c->aux_stream));
     HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
     c->dist_in_flight = true;
     return HVRT_OK;
@@ -347,7 +349,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
-    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->stats, c->long_queue, c->fill_scratch,
+    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -490,6 +492,8 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
     if (int r = ensure<uint32_t>(c, c->ranges, c->ranges_capacity, (uint64_t)c->n_tris * 3)) return r;
     if (int r = ensure<uint64_t>(c, c->block_sums, c->block_sums_capacity, 2 * n_chunks)) return r;
+    if (int r = ensure<uint32_t>(c, c->occ_bits, c->occ_bits_capacity, npad / 32)) return r;
+    c->occ_bits_valid = false;
 
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
@@ -497,7 +501,8 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(uint64_t), s));
     HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, cnt_of(c), c->ranges, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, s));
+    HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, c->occ_bits, s));
+    c->occ_bits_valid = true;
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     uint64_t h_stats[6];
     HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
@@ -546,6 +551,7 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
     if (!offsets || (n_refs && !indices)) return fail(c, HVRT_ERR_INVALID, "set_grid_csr: null array");
     if (n_refs > 0xFFFFFFFFull) return fail(c, HVRT_ERR_OVERFLOW, "set_grid_csr: too many references");
     c->has_grid = false;
+    c->occ_bits_valid = false;      // the bitmap belongs to the offsets of the last build
     c->cost_valid = false;
     (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
     set_grid_params(c, nx, ny, nz, mn, mx, vs);

@@ -220,8 +220,11 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
 constexpr uint64_t ST_AGG = 1ull << 62, ST_PFX = 2ull << 62, ST_VALUE = (1ull << 62) - 1ull;
 constexpr uint32_t ST_SPIN_LIMIT = 1u << 22;
 constexpr int SCAN_WAVES = SCAN_CHUNK / 2048;       // 16 waves of 2048 counters each
+// occ_bits (nullable): one bit per voxel, "has a list" -- the counters are in registers here anyway, and the
+// distance field's x pass then reads 1/32 of what the offsets would cost it.
 __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cnt4, uint64_t* __restrict__ status,
-                                                          uint64_t* __restrict__ aux, uint64_t* __restrict__ stats) {
+                                                          uint64_t* __restrict__ aux, uint64_t* __restrict__ stats,
+                                                          uint32_t* __restrict__ occ_bits) {
     __shared__ uint32_t s_chunk, s_w[SCAN_WAVES], s_occ[SCAN_WAVES], s_mx[SCAN_WAVES];
     __shared__ uint64_t s_base;
     if (threadIdx.x == 0) s_chunk = atomicAdd(reinterpret_cast<uint32_t*>(stats + 6), 1u);
@@ -241,6 +244,14 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cn
         excl[k] = carry + inc - tot;
         carry += __shfl(inc, 63);
         occ += (v[k].x > 0) + (v[k].y > 0) + (v[k].z > 0) + (v[k].w > 0);
+        if (occ_bits) {
+            // my four voxels' bits, then eight lanes' nibbles into one word (lanes 0, 8, 16, ... store)
+            uint32_t bits = (v[k].x > 0 ? 1u : 0u) | (v[k].y > 0 ? 2u : 0u) | (v[k].z > 0 ? 4u : 0u) | (v[k].w > 0 ? 8u : 0u);
+            bits |= (uint32_t)__shfl_down((int)bits, 1) << 4;
+            bits |= (uint32_t)__shfl_down((int)bits, 2) << 8;
+            bits |= (uint32_t)__shfl_down((int)bits, 4) << 16;
+            if ((lane & 7) == 0) occ_bits[(c * SCAN_CHUNK + (uint64_t)w * 2048u + (uint64_t)k * 256u) / 32u + (uint32_t)(lane >> 3)] = bits;
+        }
         const uint32_t m = v[k].x > v[k].y ? v[k].x : v[k].y, n = v[k].z > v[k].w ? v[k].z : v[k].w;
         const uint32_t mm = m > n ? m : n;
         mx = mx > mm ? mx : mm;
@@ -582,8 +593,10 @@ __global__ __launch_bounds__(256) void k_dist_x(const uint32_t* __restrict__ off
 // loop leaves the first / last occupied voxel of chunk c in lane c, two wave scans turn those into "last
 // occupied before" / "first occupied after" each chunk, and the second loop writes the finished bytes, one
 // dword per lane.
-__global__ __launch_bounds__(256) void k_dist_x4(const uint32_t* __restrict__ offsets, uint8_t* __restrict__ dist,
-                                                 uint32_t nx, uint64_t n_lines) {
+// BITS: occupancy comes from the bitmap k_scan left (one bit per voxel) instead of from the offsets.
+template <bool BITS>
+__global__ __launch_bounds__(256) void k_dist_x4(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ occ_bits,
+                                                 uint8_t* __restrict__ dist, uint32_t nx, uint64_t n_lines) {
     constexpr int FAR = 1 << 30;
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -595,7 +608,10 @@ __global__ __launch_bounds__(256) void k_dist_x4(const uint32_t* __restrict__ of
         auto nibble = [&](uint32_t c) -> uint32_t {
             const uint32_t i0 = c * 256u + 4u * (uint32_t)lane;
             uint32_t nib = 0;
-            if (i0 < nx) {
+            if (BITS) {
+                const uint64_t gv = line * nx + i0;                      // a multiple of 4
+                if (i0 < nx) nib = (occ_bits[gv >> 5] >> (uint32_t)(gv & 31u)) & 0xFu;
+            } else if (i0 < nx) {
                 uint32_t v[5];
 #pragma unroll
                 for (int k = 0; k < 5; ++k) v[k] = o[i0 + k];
@@ -815,11 +831,11 @@ hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, u
     return hipGetLastError();
 }
 
-hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, hipStream_t s) {
+hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, uint32_t* occ_bits, hipStream_t s) {
     // status words must start empty; the ticket (stats[6]) and the failure flag (stats[5]) were zeroed with stats
     hipError_t e = hipMemsetAsync(status_aux, 0, n_chunks * sizeof(uint64_t), s);
     if (e != hipSuccess) return e;
-    k_scan<<<(unsigned)n_chunks, SCAN_WAVES * 64, 0, s>>>((uint4*)cnt, status_aux, status_aux + n_chunks, stats);
+    k_scan<<<(unsigned)n_chunks, SCAN_WAVES * 64, 0, s>>>((uint4*)cnt, status_aux, status_aux + n_chunks, stats, occ_bits);
     const uint64_t blocks = (n_chunks + 2047) / 2048;
     k_scan_stats<<<(unsigned)(blocks > 256 ? 256 : blocks), 256, 0, s>>>(status_aux + n_chunks, n_chunks, stats);
     return hipGetLastError();
@@ -866,13 +882,14 @@ hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint
     return hipGetLastError();
 }
 
-hipError_t launch_distance_field(const uint32_t* offsets, const GridParams& g, uint8_t* dist, hipStream_t s) {
+hipError_t launch_distance_field(const uint32_t* offsets, const uint32_t* occ_bits, const GridParams& g, uint8_t* dist, hipStream_t s) {
     const uint64_t nx = (uint64_t)g.nx, ny = (uint64_t)g.ny, nz = (uint64_t)g.nz;
     {
         const uint64_t lines = ny * nz;
         uint64_t blocks = (lines + 3) / 4;
         if (blocks > 65536) blocks = 65536;
-        if (nx % 4 == 0 && nx <= 16384) k_dist_x4<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
+        if (nx % 4 == 0 && nx <= 16384 && occ_bits) k_dist_x4<true><<<(unsigned)blocks, 256, 0, s>>>(offsets, occ_bits, dist, (uint32_t)nx, lines);
+        else if (nx % 4 == 0 && nx <= 16384) k_dist_x4<false><<<(unsigned)blocks, 256, 0, s>>>(offsets, nullptr, dist, (uint32_t)nx, lines);
         else k_dist_x<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
     }
     // four lines per lane where line starts and strides are multiples of 4 (dist itself is 256-B aligned) -- but

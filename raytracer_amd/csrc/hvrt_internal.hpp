@@ -89,7 +89,8 @@ hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams&
 // in-place exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64 of scratch.
 // stats[0] <- total, stats[1] += occupied voxels, stats[2] <- longest list, stats[5] != 0: the scan gave up
 // (stats[5], stats[6] must be zero on entry)
-hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, hipStream_t s);
+// occ_bits (nullable): n_chunks x SCAN_CHUNK / 32 words, one bit per voxel "has a list"
+hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, uint32_t* occ_bits, hipStream_t s);
 hipError_t launch_fill(const uint32_t* ranges, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
                        uint32_t* indices_unsorted, uint32_t* vox_of, hipStream_t s);
 hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, uint64_t n_refs,
@@ -101,7 +102,8 @@ hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint
                             uint32_t n_tris, const uint32_t* ranges /* null: search the neighbour lists */,
                             const uint32_t* vox_of /* null: search the offsets */,
                             uint32_t* face_bits, uint64_t face_words, hipStream_t s);
-hipError_t launch_distance_field(const uint32_t* offsets, const GridParams& g, uint8_t* dist, hipStream_t s);
+// occ_bits: the bitmap launch_scan left for THESE offsets, or null (occupancy is then read from the offsets)
+hipError_t launch_distance_field(const uint32_t* offsets, const uint32_t* occ_bits, const GridParams& g, uint8_t* dist, hipStream_t s);
 hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s);
 hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* blocks x 6 + idx */,
                          uint64_t* partial_idx, int n_blocks, float* out6, hipStream_t s);
