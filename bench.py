@@ -205,7 +205,8 @@ def main():
                                "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_render",
                                "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
                                "note": "algorithmic (requested) bytes 8V+40T+20 per ray; >1 means the bytes are served "
-                                       "from cache or never requested; the binding resources are per-CU, see binding",
+                                       "from cache or never requested; what binds the kernel is per-CU: VALU issue and the vector-load "
+                                       "return path, both saturated (see binding)",
                                "binding": {k: prof[k] for k in ("valu_issue_frac", "salu_issue_frac", "td_busy_frac", "ta_busy_frac", "l2_hit_rate",
                                                                 "busy_source") if k in prof}}
             nvox = g ** 3
