@@ -405,7 +405,7 @@ def test_config2_full_size_render_rows(ctx):
     assert np.array_equal(np.broadcast_to(bg, (H, W))[~m], rgb[..., 0][~m])
 
 
-def _rows_against_oracle(ctx, tris, g, W, H, rows, spp=1, seed=0, launches=1):
+def _rows_against_oracle(ctx, tris, g, W, H, rows, spp=1, seed=0, launches=1, mode=0):
     ctx.set_mesh(tris)
     mn, mx = ctx.mesh_bounds()
     vs = capi.voxel_size(mn, mx, g, g, g)
@@ -413,8 +413,13 @@ def _rows_against_oracle(ctx, tris, g, W, H, rows, spp=1, seed=0, launches=1):
     off, idx = ctx.get_csr()
     sc = oracle.OracleScene(tris, g, g, g, mn, vs, off, idx)
     fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
-    for _ in range(launches):            # later launches pull their tiles in the order the first one measured
-        rgb, hit, t, cnt = render_both(ctx, fr, W, H, spp=spp, seed=seed)
+    try:
+        ctx.set_mode(mode)
+        sc.set_mode(mode, mx)
+        for _ in range(launches):        # later launches pull their tiles in the order the first one measured
+            rgb, hit, t, cnt = render_both(ctx, fr, W, H, spp=spp, seed=seed)
+    finally:
+        ctx.set_mode(0)
     ohit = np.zeros((len(rows), W), np.uint32)
     ot = np.zeros((len(rows), W), np.float32)
     orgb = np.zeros((len(rows), W, 3), np.float32)
@@ -439,6 +444,14 @@ def test_config3_like_full_size_render_rows(ctx):
     W, H = 3840, 2160
     rows = sorted(set(range(0, H, 24)) | set(range(1000, 1160, 2)))
     _rows_against_oracle(ctx, meshgen.skewed_statue(289, 2100), 512, W, H, rows, launches=3)
+
+
+def test_config3_like_full_size_render_rows_nearest_hit_mode(ctx):
+    """The same scene and frame in nearest-hit mode (hvrt_set_mode(1); parity unpinned by the reference, the
+    oracle's mode 1 is the checker): every 48th row and every 4th across the patch, third launch."""
+    W, H = 3840, 2160
+    rows = sorted(set(range(5, H, 48)) | set(range(1000, 1160, 4)))
+    _rows_against_oracle(ctx, meshgen.skewed_statue(289, 2100), 512, W, H, rows, launches=3, mode=1)
 
 
 def test_config4_8k_16spp_rows(ctx):
