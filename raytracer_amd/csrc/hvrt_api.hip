@@ -503,6 +503,11 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, c->occ_bits, s));
     c->occ_bits_valid = true;
+    // With the occupancy bitmap the distance field needs nothing else: it starts now, on the second stream, beside
+    // the fill (which waits on atomics, not on bandwidth).  Beside the list-ordering kernel -- where it ran before
+    // -- its streaming sweeps pushed that kernel's re-read lists out of L2 (3.1 ms for the two together at 1024^3,
+    // against 1.2 + 1.9 apart).  Grids whose x extent the bitmap kernel does not take are forked after the fill.
+    if (nx % 4 == 0 && nx <= 16384) if (int r = fork_distance_field(c, s)) return r;
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
     uint64_t h_stats[6];
     HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
@@ -520,7 +525,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipEventRecord(c->ev[3], s));
     HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, s));
     HIP_TRY(c, hipEventRecord(c->ev[4], s));
-    if (int r = fork_distance_field(c, s)) return r;     // offsets are final from here on
+    if (!c->dist_in_flight) if (int r = fork_distance_field(c, s)) return r;     // offsets are final from here on
     HIP_TRY(c, launch_sort(offsets_of(c), unsorted, vox_of, total, c->indices, c->long_queue, c->long_queue_capacity, c->stats, s));
     HIP_TRY(c, hipEventRecord(c->ev[5], s));
     c->n_refs = total;
