@@ -20,7 +20,8 @@ struct hvrt_ctx {
     int n_cus = 256;
     hipStream_t stream = nullptr;       // the stream all work is issued on (own_stream unless hvrt_set_stream)
     hipStream_t own_stream = nullptr;
-    hipStream_t aux_stream = nullptr;   // the distance field is built here, beside sort / face bits / records
+    hipStream_t aux_stream = nullptr;   // k_render_split runs here, beside k_render
+    hipStream_t df_stream = nullptr;    // the distance field is built here (lowest priority), beside fill / order / records
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dist_in_flight = false;
     hipEvent_t ev[10] = {};
@@ -230,9 +231,9 @@ int require_scene(hvrt_ctx* c) {
 int fork_distance_field(hvrt_ctx* c, hipStream_t s) {
     if (int r = ensure<uint8_t>(c, c->dist, c->dist_capacity, c->g.nvox + 64)) return r;
     HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-    HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    HIP_TRY(c, launch_distance_field(offsets_of(c), c->occ_bits_valid ? c->occ_bits : nullptr, c->g, c->dist, c->aux_stream));
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->df_stream, c->ev_fork, 0));
+    HIP_TRY(c, launch_distance_field(offsets_of(c), c->occ_bits_valid ? c->occ_bits : nullptr, c->g, c->dist, c->df_stream));
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->df_stream));
     c->dist_in_flight = true;
     return HVRT_OK;
 }
@@ -317,6 +318,11 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     c->stream = c->own_stream;
     if ((e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        if ((e = hipStreamCreateWithPriority(&c->df_stream, hipStreamNonBlocking, least)) != hipSuccess) return bail("hipStreamCreate", e);
+    }
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -349,6 +355,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->df_stream) (void)hipStreamSynchronize(c->df_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
@@ -361,6 +368,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     for (auto& ev : c->pin_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->df_stream) (void)hipStreamDestroy(c->df_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_split_fork) (void)hipEventDestroy(c->ev_split_fork);
