@@ -225,7 +225,7 @@ int require_scene(hvrt_ctx* c) {
 
 // Builds the per-reference records (and validates every CSR index against the mesh).  Falls back to the
 // indexed traversal when switched off or when the array does not fit in device memory.
-// The distance field needs only the finished offsets, so it runs on a second stream beside the kernels that
+// The distance field needs only the finished offsets, so it runs on a stream of its own beside the kernels that
 // order the lists and derive face bits and records (small grids: those kernels are a few waves each and
 // overlap almost entirely).  fork after the offsets are final, join before the build returns.
 int fork_distance_field(hvrt_ctx* c, hipStream_t s) {
@@ -511,7 +511,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, c->occ_bits, s));
     c->occ_bits_valid = true;
-    // With the occupancy bitmap the distance field needs nothing else: it starts now, on the second stream, beside
+    // With the occupancy bitmap the distance field needs nothing else: it starts now, on its own stream, beside
     // the fill (which waits on atomics, not on bandwidth).  Beside the list-ordering kernel -- where it ran before
     // -- its streaming sweeps pushed that kernel's re-read lists out of L2 (3.1 ms for the two together at 1024^3,
     // against 1.2 + 1.9 apart).  Grids whose x extent the bitmap kernel does not take are forked after the fill.
