@@ -55,6 +55,13 @@ def cpu_baseline(tris, g, mn, vs, off, idx, cam, W, H, n_rays_target=8.3e6):
         list(ex.map(work, range(threads)))
     dt = time.perf_counter() - t0
     rays = len(rows) * W
+    # one core, every 16th of those rows (SURVEY 8d asks for both)
+    rows1 = rows[::16]
+    t2 = time.perf_counter()
+    for y in rows1:
+        oracle.lib().orc_render_rows(C.byref(sc.c), C.byref(f), W, H, int(y), int(y) + 1, 1, C.c_uint32(0),
+                                     None, None, None, C.c_void_p(cnts[0].ctypes.data))
+    dt1 = time.perf_counter() - t2
     # voxel build on one core (flat CSR port of SceneCreator.cpp:197-281)
     t1 = time.perf_counter()
     oracle.voxelize(tris, g, g, g, mn, vs)
@@ -62,6 +69,7 @@ def cpu_baseline(tris, g, mn, vs, off, idx, cam, W, H, n_rays_target=8.3e6):
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{len(rows)} evenly spaced rows of the same {W}x{H} frame ({rays} rays, {dt:.2f} s); "
                       f"oracle/cpu_ref.c, one trace per pixel",
+            "value_1core": len(rows1) * W / dt1 / 1e6,   # Mrays/s, one thread, every 16th row of the sample
             "build_ms_1core": bt * 1e3 / 2.0,   # voxelize() runs the count pass twice (sizing + fill)
             }
 
