@@ -671,6 +671,79 @@ __global__ __launch_bounds__(256) void k_dist_x4(const uint32_t* __restrict__ of
     }
 }
 
+// x pass for wide grids built here (nx a multiple of 16, at least 1024; occupancy from the scan's bitmap): a lane
+// takes SIXTEEN neighbouring voxels -- one halfword of the bitmap in, one 16-byte store out -- so a wave covers
+// 1024 voxels per step and the wave-level work (two ballots, two shuffles per step) is shared by four times as
+// many voxels as in k_dist_x4; a 1024-wide line is a single step and needs none of the cross-chunk scans.
+__global__ __launch_bounds__(256) void k_dist_x16(const uint32_t* __restrict__ occ_bits, uint8_t* __restrict__ dist,
+                                                  uint32_t nx, uint64_t n_lines) {
+    constexpr int FAR = 1 << 30;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * 256u) >> 6;
+    const uint32_t n_chunks = (nx + 1023u) / 1024u;              // <= 16
+    const uint16_t* __restrict__ half = reinterpret_cast<const uint16_t*>(occ_bits);
+    for (uint64_t line = wave0; line < n_lines; line += n_waves) {
+        const uint64_t line0 = line * nx;                        // a multiple of 16
+        auto bits16 = [&](uint32_t c) -> uint32_t {
+            const uint32_t i0 = c * 1024u + 16u * (uint32_t)lane;
+            return i0 < nx ? (uint32_t)half[(line0 + i0) >> 4] : 0u;
+        };
+        // first / last occupied voxel of chunk c -> lane c, then "last before" / "first after" every chunk
+        int before = -FAR, after = FAR;
+        if (n_chunks > 1) {
+            int my_first = FAR, my_last = -FAR;
+            for (uint32_t c = 0; c < n_chunks; ++c) {
+                const uint32_t m = bits16(c);
+                const unsigned long long H = __ballot(m != 0);
+                if (H) {
+                    const int fl = __builtin_ctzll(H), ll = 63 - __builtin_clzll(H);
+                    const int lo = m ? __builtin_ctz(m) : 0, hi = m ? 31 - __builtin_clz(m) : 0;
+                    const int first = (int)(c * 1024u) + 16 * fl + __shfl(lo, fl);
+                    const int last = (int)(c * 1024u) + 16 * ll + __shfl(hi, ll);
+                    if (lane == (int)c) { my_first = first; my_last = last; }
+                }
+            }
+            int inc_last = my_last, inc_first = my_first;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const int a = __shfl_up(inc_last, d), b = __shfl_down(inc_first, d);
+                if (lane >= d) inc_last = a > inc_last ? a : inc_last;
+                if (lane + d < 64) inc_first = b < inc_first ? b : inc_first;
+            }
+            before = __shfl_up(inc_last, 1); after = __shfl_down(inc_first, 1);
+            if (lane == 0) before = -FAR;
+            if (lane == 63) after = FAR;
+        }
+        for (uint32_t c = 0; c < n_chunks; ++c) {
+            const uint32_t m = bits16(c);
+            const unsigned long long H = __ballot(m != 0);
+            const int lo = m ? __builtin_ctz(m) : 0, hi = m ? 31 - __builtin_clz(m) : 0;
+            const int left = n_chunks > 1 ? __shfl(before, (int)c) : -FAR, right = n_chunks > 1 ? __shfl(after, (int)c) : FAR;
+            const unsigned long long Hb = H & ((1ull << lane) - 1ull);        // lanes below me with an occupied voxel
+            const unsigned long long Ha = H & ~((2ull << lane) - 1ull);       // lanes above me
+            const int lb = Hb ? 63 - __builtin_clzll(Hb) : lane, la = Ha ? __builtin_ctzll(Ha) : lane;
+            const int hi_b = __shfl(hi, lb), lo_a = __shfl(lo, la);
+            const int cbase = (int)(c * 1024u);
+            const int prev_other = Hb ? cbase + 16 * lb + hi_b : left;
+            const int next_other = Ha ? cbase + 16 * la + lo_a : right;
+            const int base = cbase + 16 * lane;
+            uint32_t word[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t mlo = m & ((2u << k) - 1u), mhi = m >> k;
+                const int prev = mlo ? base + 31 - __builtin_clz(mlo) : prev_other;
+                const int next = mhi ? base + k + __builtin_ctz(mhi) : next_other;
+                const int i = base + k;
+                int dmin = i - prev < next - i ? i - prev : next - i;
+                dmin = dmin > 255 ? 255 : dmin;
+                word[k >> 2] |= (uint32_t)dmin << (8 * (k & 3));
+            }
+            if ((uint32_t)base < nx) *reinterpret_cast<uint4*>(dist + line0 + (uint32_t)base) = make_uint4(word[0], word[1], word[2], word[3]);
+        }
+    }
+}
+
 // y and z passes: one lane per line (lines are indexed so that neighbouring lanes are neighbouring x: every
 // access of a wave is one contiguous run); sixteen loads in flight per lane.  With W = 4 a lane carries four
 // neighbouring lines in one dword (needs the line starts and the stride to be multiples of 4).
@@ -888,7 +961,8 @@ hipError_t launch_distance_field(const uint32_t* offsets, const uint32_t* occ_bi
         const uint64_t lines = ny * nz;
         uint64_t blocks = (lines + 3) / 4;
         if (blocks > 65536) blocks = 65536;
-        if (nx % 4 == 0 && nx <= 16384 && occ_bits) k_dist_x4<true><<<(unsigned)blocks, 256, 0, s>>>(offsets, occ_bits, dist, (uint32_t)nx, lines);
+        if (nx % 16 == 0 && nx >= 1024 && nx <= 16384 && occ_bits) k_dist_x16<<<(unsigned)blocks, 256, 0, s>>>(occ_bits, dist, (uint32_t)nx, lines);
+        else if (nx % 4 == 0 && nx <= 16384 && occ_bits) k_dist_x4<true><<<(unsigned)blocks, 256, 0, s>>>(offsets, occ_bits, dist, (uint32_t)nx, lines);
         else if (nx % 4 == 0 && nx <= 16384) k_dist_x4<false><<<(unsigned)blocks, 256, 0, s>>>(offsets, nullptr, dist, (uint32_t)nx, lines);
         else k_dist_x<<<(unsigned)blocks, 256, 0, s>>>(offsets, dist, (uint32_t)nx, lines);
     }

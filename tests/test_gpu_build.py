@@ -62,6 +62,10 @@ FIXTURES = {
     "one_triangle": lambda: (meshgen.to_aos(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0.5]]], np.float32)), (5, 5, 5)),
     "single_voxel_grid": lambda: (meshgen.cube_sphere(6), (1, 1, 1)),
     "flat_grid": lambda: (meshgen.cube_sphere(10), (64, 64, 1)),
+    # wide grids: the distance field's x pass takes 16 voxels per lane from nx = 1024 on (one, three, two steps per line)
+    "wide_1024": lambda: (meshgen.random_soup(300, 3, extent=1.0, size=0.05) * np.array([40, 1, 1] * 3 + [1, 1, 1], np.float32), (1024, 6, 5)),
+    "wide_2064": lambda: (meshgen.random_soup(200, 4, extent=1.0, size=0.04) * np.array([80, 1, 1] * 3 + [1, 1, 1], np.float32), (2064, 3, 4)),
+    "wide_1040_sparse": lambda: (meshgen.random_soup(6, 5, extent=1.0, size=0.02) * np.array([60, 1, 1] * 3 + [1, 1, 1], np.float32), (1040, 2, 2)),
 }
 
 
