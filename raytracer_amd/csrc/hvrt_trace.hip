@@ -426,7 +426,7 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
 // ABORT: the variant for launches without tile history (see "gives up" below); launches with history run the
 // plain one -- the bookkeeping costs 4 % of a config 2 frame, and history already sends long tiles elsewhere.
 template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_render(SceneDev sc, RenderArgs ra) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_render(SceneDev sc, RenderArgs ra) {
     const int lane = threadIdx.x & 63;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
@@ -764,7 +764,7 @@ hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsig
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
                               uint32_t* wants_split, hipStream_t s) {
     const unsigned blocks = (n_tiles + 255u) / 256u;
-    const uint32_t slots = (uint32_t)n_cus * 20u;          // k_render runs 5 waves per SIMD
+    const uint32_t slots = (uint32_t)n_cus * 28u;          // k_render runs 7 waves per SIMD
     may_split = may_split && n_tiles <= 0x0FFFFFFFu;       // 16 items per tile in a 32-bit count
     k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count);
     k_order_scan<<<2, 1024, 0, s>>>(block_count, blocks, may_split, wants_split);
