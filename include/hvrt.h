@@ -205,6 +205,21 @@ int hvrt_render_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int w
                             int spp, uint32_t seed, int tile_rows, int part, int n_parts,
                             void* d_rgb, void* d_hit_id, void* d_t, void* d_counters);
 
+/* hvrt_render_part_device for callers that cannot allocate -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference (which allocates a std::vector per
+ * render, OctreeLikeRayTracer.cpp:90).  Same arguments, same results bit for bit; what hvrt_render_part_device keeps
+ * in context-owned, grow-on-demand device buffers (work-queue head, per-tile durations, the camera frame) lives here
+ * in a fixed array inside the library's device image: 4 MiB + 256 bytes per GPU, held until the process ends.
+ * Calls no hipMalloc / hipFree (nor anything else that allocates).  Limits and caveats:
+ *   - at most 2^20 tiles of 8x8 pixels in the rendered part (a 7680x4320 frame has 518 400); larger -> HVRT_ERR_INVALID;
+ *   - no tile history is kept or used (every call schedules like a first launch), so it is a few per cent slower
+ *     than repeated hvrt_render_part_device calls of one shape, and over-long tiles are not split;
+ *   - every call on a GPU, from any context, shares that GPU's array: calls that overlap on one GPU race.
+ * Asynchronous on the context's stream. */
+int hvrt_render_part_device_noalloc(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int width, int height,
+                                    int spp, uint32_t seed, int tile_rows, int part, int n_parts,
+                                    void* d_rgb, void* d_hit_id, void* d_t, void* d_counters);
+
 /* Batch form of hvrt_render_part_device: n_frames camera frames (1..HVRT_MAX_BATCH_FRAMES, host array), ONE
  * kernel launch whose work queue spans the tiles of every frame.  Frame f's rows of this part go to
  * d_rgb + f * slab_rows * width * 12 bytes (d_hit_id / d_t: * 4 bytes); slab_rows >= hvrt_part_rows().

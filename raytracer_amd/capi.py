@@ -24,7 +24,7 @@ SYMBOLS = [
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
-    "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace",
+    "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc",
 ]
 
 
@@ -106,6 +106,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp]
     lib.hvrt_render_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32,
                                             C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.hvrt_render_part_device_noalloc.argtypes = lib.hvrt_render_part_device.argtypes
     lib.hvrt_render_batch_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                                   C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_quantise_rgb8_device.argtypes = [vp, vp, C.c_uint64, vp]
@@ -311,6 +312,14 @@ class Context:
         vp = lambda p: C.c_void_p(p) if p else None
         self._ck(self._lib.hvrt_render_part_device(self._h, C.byref(frame), width, height, spp, seed, tile_rows,
                                                    part, n_parts, vp(d_rgb), vp(d_hit), vp(d_t), vp(d_counters)))
+
+    def render_part_device_noalloc(self, frame: CameraFrame, width: int, height: int, spp: int, seed: int,
+                                   tile_rows: int, part: int, n_parts: int,
+                                   d_rgb: int = 0, d_hit: int = 0, d_t: int = 0, d_counters: int = 0):
+        """render_part_device through the entry point that allocates nothing (fixed scratch inside libhvrt)."""
+        vp = lambda p: C.c_void_p(p) if p else None
+        self._ck(self._lib.hvrt_render_part_device_noalloc(self._h, C.byref(frame), width, height, spp, seed, tile_rows,
+                                                           part, n_parts, vp(d_rgb), vp(d_hit), vp(d_t), vp(d_counters)))
 
     def render_batch_part_device(self, frames, width: int, height: int, spp: int, seed: int,
                                  tile_rows: int, part: int, n_parts: int, slab_rows: int,

@@ -1,6 +1,7 @@
 // hvrt_api.hip -- the C ABI of libhvrt (include/hvrt.h): context, device memory, kernel sequencing.
-// Host code only; the kernels live in hvrt_build.hip / hvrt_trace.hip.  No CPU fallback exists:
-// every entry point either runs on the GPU or returns an error.
+// Host code (plus the device-side scratch array of the entry point that allocates nothing and the one-wave
+// kernel that fills its camera slot); the kernels live in hvrt_build.hip / hvrt_trace.hip.  No CPU fallback
+// exists: every entry point either runs on the GPU or returns an error.
 #include "hvrt_internal.hpp"
 
 #include <float.h>
@@ -103,9 +104,32 @@ struct hvrt_ctx {
 
     int mode = 0;   // hvrt_set_mode
 
+    // this device's copy of the file-scope scratch array (hvrt_render_part_device_noalloc), resolved in hvrt_create
+    unsigned char* noalloc_scratch = nullptr;
+
     hvrt_timings tm = {};
     bool render_pending = false;   // ev[6..7] recorded by an asynchronous render, not yet read
 };
+
+// ---- scratch of hvrt_render_part_device_noalloc -------------------------------------------------------------
+// Everything that entry point's kernels need beyond the caller's inputs and outputs: the work-queue head, the sum
+// of tile durations, the camera frame (the kernel reads it with scalar loads from device memory) and one duration
+// word per 8x8 tile.  One copy per GPU, held until the process ends; `scratch` is only a host-side stand-in for it --
+// the device address comes from hipGetSymbolAddress (hvrt_create, with the device current) and is what every use
+// below goes through.
+constexpr uint32_t NOALLOC_MAX_TILES = 1u << 20;     // 8x8-pixel tiles per call: 7680x4320 has 518 400
+constexpr size_t NOALLOC_QUEUE_HEAD = 0;             // u32 queue head, u32 unused
+constexpr size_t NOALLOC_COST_SUM = 8;               // u64
+constexpr size_t NOALLOC_FRAME = 64;                 // hvrt_camera_frame, 48 bytes
+constexpr size_t NOALLOC_TILE_COST = 256;            // u32 x NOALLOC_MAX_TILES
+constexpr size_t NOALLOC_BYTES = NOALLOC_TILE_COST + 4ull * NOALLOC_MAX_TILES;     // 4 MiB + 256 B
+static __device__ __align__(256) unsigned char scratch[NOALLOC_BYTES];
+
+// the camera frame travels as a kernel argument (no staging buffer, no copy from pageable memory)
+__global__ __launch_bounds__(64) void k_store_frame(hvrt_camera_frame f, float* __restrict__ dst) {
+    const float* src = f.origin;     // the struct is twelve consecutive floats
+    if (threadIdx.x < sizeof(hvrt_camera_frame) / sizeof(float)) dst[threadIdx.x] = src[threadIdx.x];
+}
 
 namespace {
 
@@ -343,6 +367,8 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_ABORT_US")) c->abort_clocks = atoll(v) > 0 ? atoll(v) * 2400 : (1ll << 62);
     if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
+    // this device's copy of the scratch array (every GPU holds its own, at its own address)
+    if ((e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_i, 2048 * 6 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_out, 256)) != hipSuccess) return bail("hipMalloc", e);
@@ -807,6 +833,55 @@ int hvrt_render_part_device(hvrt_ctx* c, const hvrt_camera_frame* frame, int wid
     const int rows = hvrt_part_rows(height, tile_rows, part, n_parts);
     return hvrt_render_batch_part_device(c, frame, 1, width, height, spp, seed, tile_rows, part, n_parts, rows,
                                          d_rgb, d_hit_id, d_t, d_counters);
+}
+
+int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp,
+                                    uint32_t seed, int tile_rows, int part, int n_parts, void* d_rgb, void* d_hit_id,
+                                    void* d_t, void* d_counters) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (int r = require_scene(c)) return r;
+    if (!frame) return fail(c, HVRT_ERR_INVALID, "render: null camera frame");
+    if (width < 1 || height < 1 || (uint64_t)width * height > 0x7FFFFFFFull)
+        return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
+    if (spp < 1) return fail(c, HVRT_ERR_INVALID, "render: spp must be >= 1");
+    if (tile_rows < 1 || n_parts < 1 || part < 0 || part >= n_parts)
+        return fail(c, HVRT_ERR_INVALID, "render: bad partition (tile_rows %d, part %d of %d)", tile_rows, part, n_parts);
+    const int local_rows = hvrt_part_rows(height, tile_rows, part, n_parts);
+    const uint64_t n_tiles = render_tile_count(width, local_rows, 1);
+    if (n_tiles > NOALLOC_MAX_TILES)
+        return fail(c, HVRT_ERR_INVALID, "render (noalloc): %llu tiles of 8x8 pixels exceed the fixed scratch of %u tiles "
+                    "(%d x %d pixels in this part); use hvrt_render_part_device", (unsigned long long)n_tiles,
+                    NOALLOC_MAX_TILES, width, local_rows);
+    if (!c->noalloc_scratch) return fail(c, HVRT_ERR_HIP, "render (noalloc): the scratch array was not resolved");
+    hipStream_t s = c->stream;
+    unsigned char* sp = c->noalloc_scratch;      // device address of this GPU's array, never the symbol itself
+    hvrt_camera_frame* d_frame = (hvrt_camera_frame*)(sp + NOALLOC_FRAME);
+
+    RenderArgs ra = {};
+    ra.frames = d_frame; ra.n_frames = 1;
+    ra.width = width; ra.height = height; ra.spp = spp; ra.seed = seed;
+    ra.nearest = c->mode;
+    ra.tile_rows = tile_rows; ra.part = part; ra.n_parts = n_parts;
+    ra.local_rows = local_rows; ra.slab_rows = local_rows;
+    ra.rgb = (float*)d_rgb; ra.hit_id = (uint32_t*)d_hit_id; ra.t = (float*)d_t;
+    ra.counters = (unsigned long long*)d_counters;
+    ra.tile_counter = (uint32_t*)(sp + NOALLOC_QUEUE_HEAD);
+    ra.order = nullptr;                 // no history is kept between these calls: rows of tiles from the middle outwards
+    ra.split_tiles = nullptr; ra.n_split = nullptr;
+    ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_clocks = 0;   // the plain kernel: no tile is handed on
+    ra.tile_cost = (uint32_t*)(sp + NOALLOC_TILE_COST);
+    ra.cost_sum = (unsigned long long*)(sp + NOALLOC_COST_SUM);
+    // the array keeps the last call's contents: the queue head and the duration sum must start at zero (the
+    // duration words and the camera slot are overwritten before they are read)
+    HIP_TRY(c, hipMemsetAsync(sp, 0, 16, s));
+    k_store_frame<<<1, 64, 0, s>>>(*frame, (float*)d_frame);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, false, s));
+    HIP_TRY(c, hipEventRecord(c->ev[7], s));
+    c->render_pending = true;
+    return HVRT_OK;
 }
 
 int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,
