@@ -282,7 +282,9 @@ int make_ref_records_inner(hvrt_ctx* c, hipStream_t s, bool validate) {
     if (want) {
         if (c->ref_rec_capacity < c->n_refs * 3) {
             if (c->ref_rec) { (void)hipFree(c->ref_rec); c->ref_rec = nullptr; c->ref_rec_capacity = 0; }
-            hipError_t e = hipMalloc((void**)&c->ref_rec, c->n_refs * 48);
+            // + 64 float4s: the traversal fetches a list chunk with one 16-byte load per lane of the wave, and the
+            // lanes behind the last record of the last list read (and ignore) what follows it
+            hipError_t e = hipMalloc((void**)&c->ref_rec, c->n_refs * 48 + 64 * sizeof(float4));
             if (e == hipSuccess) c->ref_rec_capacity = c->n_refs * 3;
             else { (void)hipGetLastError(); c->ref_rec = nullptr; }   // does not fit: indexed mode
         }

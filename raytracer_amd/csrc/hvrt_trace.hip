@@ -348,6 +348,239 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
     return r;
 }
 
+// ---- wave-synchronous traversal on per-reference records (k_render, k_trace) ---------------------------
+// The same walk as trace_ray<..., INLINE = true, ..., RAYS = 64>, written so that the wave's control flow is
+// UNIFORM: the outer loop, the list loop and the chunk loop branch on ballots, and a ray that has ended (or a
+// lane that never had one) stays in them with alive == false.  Every lane therefore still executes at the point
+// where a list chunk is fetched, which is what the fast path needs:
+//
+//   In nine of ten test iterations of a coherent 8x8 tile all lanes test the SAME list entry (the rays of a tile
+//   leave from one clamped voxel and stay together), and a vector load costs the CU's texture path the same
+//   ~16 clocks per wave whether its 64 lanes name 64 addresses or one (scripts/ubench/l1_rate.hip): three loads
+//   per entry and wave kept that path 97 % busy.  When all lanes that have work are in the same chunk of the same
+//   list, the chunk's records (21 x 48 B = 63 lanes x 16 B, consecutive) are fetched by ONE coalesced 16-byte
+//   load over the wave, and each entry's nine floats and id are then broadcast to scalar registers with
+//   v_readlane and used as scalar operands of the test: one vector load per chunk instead of three per entry.
+//   The entries are taken in ascending order over the union of the lanes' to-do bits (face-bit skips differ
+//   between lanes that entered the voxel through different faces), so "the last entry that hits wins" holds.
+//   Lanes in different voxels fall back to the per-lane loads for that round.
+//
+// Arithmetic, voxel sequence, test order and counters are trace_ray's (and so the reference's); only who fetches
+// the bytes differs.  ABORT gives up for the whole wave at once (the clock is a scalar).
+constexpr uint32_t COOP_CHUNK = 21;     // entries per cooperative chunk: 63 lanes x 16 B = 21 records of 48 B
+
+__device__ __forceinline__ uint32_t wave_or(uint32_t v) {
+    // OR over the 64 lanes (all must be active): two quad swaps, the two row mirrors, then the four rows' values
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror
+    return (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) |
+                      __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
+}
+__device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+template <bool COUNT, bool NEAREST, bool ABORT>
+__device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, V3 d, bool alive, float4* __restrict__ win, long long deadline = 0) {
+    const GridParams& g = sc.g;
+    const int lane = (int)(threadIdx.x & 63u);
+    TraceResult r;
+    r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
+
+    V3 st = o;
+    if (NEAREST) {
+        const float ivx = 1.0f / d.x, ivy = 1.0f / d.y, ivz = 1.0f / d.z;
+        const float tx1 = (g.mnx - o.x) * ivx, tx2 = (g.bxx - o.x) * ivx;
+        const float ty1 = (g.mny - o.y) * ivy, ty2 = (g.bxy - o.y) * ivy;
+        const float tz1 = (g.mnz - o.z) * ivz, tz2 = (g.bxz - o.z) * ivz;
+        const float tn = max2(max2(min2(tx1, tx2), min2(ty1, ty2)), min2(tz1, tz2));
+        const float tf = min2(min2(max2(tx1, tx2), max2(ty1, ty2)), max2(tz1, tz2));
+        alive = alive && (tf >= tn && tf >= 0.0f);
+        const float t0 = max2(tn, 0.0f);
+        st = { o.x + d.x * t0, o.y + d.y * t0, o.z + d.z * t0 };
+    }
+    const int ix = clampi(f2i((st.x - g.mnx) / g.vsx), 0, g.nx - 1);
+    const int iy = clampi(f2i((st.y - g.mny) / g.vsy), 0, g.ny - 1);
+    const int iz = clampi(f2i((st.z - g.mnz) / g.vsz), 0, g.nz - 1);
+    const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;
+    const float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
+    float tmx = ((g.mnx + (float)(px ? ix + 1 : ix) * g.vsx) - o.x) / d.x;
+    float tmy = ((g.mny + (float)(py ? iy + 1 : iy) * g.vsy) - o.y) / d.y;
+    float tmz = ((g.mnz + (float)(pz ? iz + 1 : iz) * g.vsz) - o.z) / d.z;
+    int rx = px ? g.nx - 1 - ix : ix;
+    int ry = py ? g.ny - 1 - iy : iy;
+    const int zsum = (pz ? g.nz - 1 - iz : iz) + rx + ry;
+    int tot = 0;
+    const uint32_t plane = (uint32_t)g.nx * (uint32_t)g.ny;
+    const uint32_t fsx = px ? 1u : 0xFFFFFFFFu;
+    const uint32_t fsy = py ? (uint32_t)g.nx : 0u - (uint32_t)g.nx;
+    const uint32_t fsz = pz ? plane : 0u - plane;
+    uint32_t f = (uint32_t)ix + (uint32_t)g.nx * (uint32_t)iy + plane * (uint32_t)iz;
+    const uint32_t* __restrict__ offs = sc.offsets;
+    const uint32_t fw = (uint32_t)sc.face_words;
+    const uint32_t facex = (px ? 0u : 1u) * fw, facey = (py ? 2u : 3u) * fw, facez = (pz ? 4u : 5u) * fw;
+    uint32_t last = 0;
+#ifndef HVRT_DIAG
+    if (COUNT) r.nv = alive ? 1u : 0u;
+#endif
+
+#define HVRT_STEP()                                                             \
+    do {                                                                        \
+        const bool cxy = tmx < tmy;                                             \
+        const bool c2 = (cxy ? tmx : tmy) < tmz;                                \
+        const bool stx = cxy && c2, sty = !cxy && c2;                           \
+        tmx = stx ? tmx + tdx : tmx;                                            \
+        tmy = sty ? tmy + tdy : tmy;                                            \
+        tmz = c2 ? tmz : tmz + tdz;                                             \
+        rx -= stx ? 1 : 0; ry -= sty ? 1 : 0;                                   \
+        last = c2 ? (cxy ? fsx : fsy) : fsz;                                    \
+        f += last;                                                              \
+    } while (0)
+#define HVRT_IN_GRID() ((rx | ry | (zsum - tot - rx - ry)) >= 0)
+#define HVRT_NEAREST_DONE()                                                     \
+    (r.tri != HVRT_MISS && r.t <= (((tmx < tmy ? tmx : tmy) < tmz) ? (tmx < tmy ? tmx : tmy) : tmz))
+
+    const uint8_t* __restrict__ dist = sc.dist;
+    for (;;) {
+        // phase 1 (as in trace_ray): walk to the next occupied voxel, k empty-space steps at a time
+        bool search = alive;
+        bool done = false;
+        for (;;) {
+            uint32_t dd = 255u;
+            if (search) dd = dist[f];
+            search = search && dd != 0u;
+            if (any_lane(search) == 0ull) break;
+            const uint32_t ds = search ? dd : 255u;
+            int k = 1;
+            if (any_lane(ds < 2u) == 0ull) {
+                k = 2;
+                if (any_lane(ds < 4u) == 0ull) {
+                    k = 4;
+                    if (any_lane(ds < 8u) == 0ull) {
+                        k = 8;
+                        if (any_lane(ds < 16u) == 0ull) k = any_lane(ds < 32u) == 0ull ? 32 : 16;
+                    }
+                }
+            }
+            if (search) {
+                if (COUNT || NEAREST) {
+                    bool going = true;
+                    for (int i = 0; i < k; ++i) {
+                        if (NEAREST) { done = done || HVRT_NEAREST_DONE(); going = going && !done; }
+                        HVRT_STEP();
+                        ++tot;
+                        going = going && HVRT_IN_GRID();
+#ifndef HVRT_DIAG
+                        if (COUNT) r.nv += going ? 1u : 0u;
+#endif
+                    }
+                    search = going;
+                } else {
+                    for (int i = 0; i < k; ++i) HVRT_STEP();
+                    tot += k;
+                    search = HVRT_IN_GRID();
+                }
+            }
+        }
+        if (NEAREST) alive = alive && !done;
+        alive = alive && HVRT_IN_GRID();
+        if (any_lane(alive) == 0ull) break;
+        uint32_t b0 = 0, b1 = 0;
+        if (alive) { const uint32_t* pv = offs + f; b0 = pv[0]; b1 = pv[1]; }
+        const bool entered = last != 0u;
+        const uint32_t face = (last == fsx && g.nx > 1) ? facex : (last == fsy && g.ny > 1) ? facey : facez;
+        // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
+        const uint32_t n = b1 - b0;       // 0 for lanes without a ray
+        uint32_t c = 0;
+        for (;;) {
+            const bool work = c < n;
+            const unsigned long long wm = any_lane(work);
+            if (wm == 0ull) break;
+            if (ABORT) {
+                // the wave gives the tile up as a whole: nothing of it is kept
+                if (any_lane(work && c != 0u) != 0ull && clock64() > deadline) { r.tri = HVRT_ABORTED; return r; }
+            }
+            const uint32_t base = b0 + c;
+            uint32_t todo = 0;
+            if (work) {
+                uint32_t skip = 0;
+                if (entered) {
+                    const uint32_t* __restrict__ fb = sc.face_bits + (face + (base >> 5));
+                    skip = __builtin_amdgcn_alignbit(fb[1], fb[0], base & 31u);
+                }
+                const uint32_t left = n - c;
+                todo = ~skip & (left >= COOP_CHUNK ? ((1u << COOP_CHUNK) - 1u) : ((1u << left) - 1u));
+            }
+            const uint32_t ubase = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(wm));
+            if (any_lane(work && base != ubase) == 0ull) {
+                // every lane with work is in this chunk of this list (same voxel, so same list length): one coalesced
+                // fetch for the wave, parked in the wave's LDS window; every lane then tests the entries that ANY lane
+                // has to test (an entry one lane skips was tested by that ray one voxel ago and missed, so testing it
+                // again changes nothing), reading each record from LDS at a wave-uniform address (a broadcast)
+                const float4 A = sc.ref_rec[3ull * ubase + (uint32_t)lane];
+                uint32_t um = wave_or(todo);
+#ifdef HVRT_DIAG   // diagnostic build only: what the two counters mean depends on HVRT_DIAG (scripts/diag_counts.py)
+                if (COUNT && lane == 0) {
+                    if (HVRT_DIAG == 11) r.nv += 64;                                    // cooperative chunks
+                    if (HVRT_DIAG == 12) r.nv += 64 * (uint32_t)__builtin_popcount(um);   // cooperative test iterations
+                    if (HVRT_DIAG == 13) r.nv += 64 * (uint32_t)__builtin_popcount(um);
+                }
+                if (COUNT && HVRT_DIAG == 13) r.nt += (uint32_t)__builtin_popcount(todo);   // tests the lanes wanted
+#endif
+                win[lane] = A;
+                if (work) {
+                    while (um) {
+                        const int k = __builtin_ctz(um);
+                        um &= um - 1u;
+                        const float4* __restrict__ rec = win + 3 * k;
+                        const float4 c0 = rec[0], c1 = rec[1];
+                        const float2 c2 = *reinterpret_cast<const float2*>(rec + 2);
+                        ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, o, d, [&](float t) {
+                            if (!NEAREST || t < r.t) { r.tri = __float_as_uint(c2.y); r.t = t; }
+                        });
+                    }
+                }
+            } else {
+#ifdef HVRT_DIAG
+                if (COUNT && HVRT_DIAG == 11 && lane == 0) r.nt += 64;                  // per-lane (fallback) chunks
+#endif
+                while (todo) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(todo);
+                    todo &= todo - 1;
+#ifdef HVRT_DIAG
+                    if (COUNT && HVRT_DIAG == 12 && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) r.nt += 64;   // fallback wave iterations
+#endif
+                    const float4* __restrict__ rec = sc.ref_rec + 3ull * (base + k);
+                    const float4 c0 = rec[0], c1 = rec[1];
+                    const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
+                    ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, [&](float t) {
+                        if (!NEAREST || t < r.t) { r.tri = __float_as_uint(reinterpret_cast<const float*>(rec + 2)[1]); r.t = t; }
+                    });
+                }
+            }
+            if (work) c += COOP_CHUNK;
+        }
+#ifndef HVRT_DIAG
+        if (COUNT) r.nt += n;
+#endif
+        if (NEAREST) { if (alive && HVRT_NEAREST_DONE()) alive = false; }
+        else if (r.tri != HVRT_MISS) alive = false;      // :326-329
+        if (alive) {
+            HVRT_STEP();
+            ++tot;
+            alive = HVRT_IN_GRID();
+#ifndef HVRT_DIAG
+            if (COUNT) r.nv += alive ? 1u : 0u;
+#endif
+        }
+        if (any_lane(alive) == 0ull) break;
+    }
+#undef HVRT_IN_GRID
+#undef HVRT_STEP
+#undef HVRT_NEAREST_DONE
+    return r;
+}
+
 // computeShading (OctreeLikeRayTracer.cpp:27-40) + LambertianShader (Shaders.cpp:4-22): with
 // r=g=b=kd=1 and inShadow=0 each channel is exactly 0.1f + max(0, N.L).
 __device__ __forceinline__ V3 shade(const SceneDev& sc, const TraceResult& r, V3 o, float v) {
@@ -390,7 +623,7 @@ struct PixelResult {
 };
 template <bool COUNT, bool INLINE, bool NEAREST, int RAYS, bool ABORT>
 __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArgs& ra, const hvrt_camera_frame* __restrict__ cf,
-                                             int x, int y, long long clk0, PixelResult& out) {
+                                             int x, int y, bool alive, float4* __restrict__ win, long long clk0, PixelResult& out) {
     const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };          // wave-uniform: scalar loads
     const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
     const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
@@ -403,7 +636,11 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
         const float u = ((float)x + jx) / (float)ra.width;
         const float v = ((float)y + jy) / (float)ra.height;
         const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
-        const TraceResult r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, clk0 + ra.abort_clocks * (s + 1));
+        TraceResult r;
+        // the wave-synchronous walk wants every lane of the wave in the call, with or without a ray (alive);
+        // the per-lane walks are only ever called by lanes that have one
+        if constexpr (INLINE && RAYS == 64) r = trace_ray_wave<COUNT, NEAREST, ABORT>(sc, org, d, alive, win, clk0 + ra.abort_clocks * (s + 1));
+        else r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, clk0 + ra.abort_clocks * (s + 1));
         if (ABORT && r.tri == HVRT_ABORTED) return false;
         const V3 c = shade(sc, r, org, v);
         if (ra.spp == 1) acc = c; else acc = add(acc, c);
@@ -427,6 +664,7 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
 // plain one -- the bookkeeping costs 4 % of a config 2 frame, and history already sends long tiles elsewhere.
 template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_render(SceneDev sc, RenderArgs ra) {
+    __shared__ float4 lds_win[4][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
     const int lane = threadIdx.x & 63;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
@@ -479,8 +717,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         bool gave_up = false;
         PixelResult px;
         px.nv = px.nt = 0;
-        if (x < ra.width && lr < ra.local_rows && y < ra.height) {
-            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, clk0, px);
+        const bool inside = x < ra.width && lr < ra.local_rows && y < ra.height;
+        if constexpr (INLINE) {
+            // wave-synchronous walk: lanes outside the image come along without a ray; giving up is wave-wide
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, inside, lds_win[threadIdx.x >> 6], clk0, px);
+            if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr, x, px);
+        } else if (inside) {
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, true, nullptr, clk0, px);
             // the wave decides; a lane that finished its pixel holds its stores back until then
             if (!ABORT || any_lane(gave_up) == 0ull) store_pixel(ra, fi, lr, x, px);
         }
@@ -537,7 +780,7 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
         const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
             PixelResult px;
-            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, x, y, clk0, px);
+            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, x, y, true, nullptr, clk0, px);
             if (slice == 0) {
                 store_pixel(ra, fi, lr, x, px);
                 if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
@@ -649,12 +892,19 @@ template <bool INLINE, bool NEAREST>
 __global__ __launch_bounds__(256) void k_trace(SceneDev sc, const float* __restrict__ origins,
                                                const float* __restrict__ dirs, uint32_t n,
                                                hvrt_hit* __restrict__ out, unsigned long long* counters) {
+    __shared__ float4 lds_win[4][64];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     uint64_t nv = 0, nt = 0;
+    V3 o = { 0.0f, 0.0f, 0.0f }, d = { 0.0f, 0.0f, 0.0f };
     if (i < n) {
-        const V3 o = { origins[3ull * i], origins[3ull * i + 1], origins[3ull * i + 2] };
-        const V3 d = { dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2] };
-        const TraceResult r = trace_ray<true, INLINE, NEAREST>(sc, o, d);
+        o = { origins[3ull * i], origins[3ull * i + 1], origins[3ull * i + 2] };
+        d = { dirs[3ull * i], dirs[3ull * i + 1], dirs[3ull * i + 2] };
+    }
+    TraceResult r;
+    r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
+    if constexpr (INLINE) r = trace_ray_wave<true, NEAREST, false>(sc, o, d, i < n, lds_win[threadIdx.x >> 6]);    // all 64 lanes take part
+    else if (i < n) r = trace_ray<true, INLINE, NEAREST>(sc, o, d);
+    if (i < n) {
         hvrt_hit h;
         h.hit = r.tri != HVRT_MISS;
         h.t = r.t;

@@ -2,7 +2,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["HVRT_LIB"] = os.path.join(ROOT, "raytracer_amd", "lib", "libhvrt_diag.so")
+os.environ.setdefault("HVRT_LIB", os.path.join(ROOT, "raytracer_amd", "lib", "libhvrt_diag.so"))
 import numpy as np
 import raytracer_amd as ra
 from raytracer_amd import capi, meshgen
@@ -21,6 +21,8 @@ pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
 cam = capi.make_camera_frame(pos, la, up, fov, asp)
 cnt = ctx.render(cam, W, H)[3]
 n = W * H
+print(f"raw counters / rays: first {cnt[0]/n:.3f} second {cnt[1]/n:.3f}   (DIAG 11: cooperative | per-lane chunks per ray slot; "
+      f"12: cooperative | per-lane wave test iterations per ray slot; 13: cooperative iterations | tests the lanes wanted)")
 print(f"[DIAG=2: second/first = share of wave iterations whose lanes all test one entry: {cnt[1]/max(cnt[0],1):.3f}]")
 print(f"tests executed per ray {cnt[1]/n:.2f}; wave test iterations per ray-slot {cnt[0]/n:.2f} (x64 lanes)")
 ctx.close()
