@@ -15,10 +15,12 @@ namespace hvrt {
 namespace {
 
 constexpr float EPS = FLT_EPSILON;   // GeometryUtils.cpp:64
+#ifdef HVRT_DIAG
+constexpr bool HVRT_DIAG_BUILD = true;
+#else
+constexpr bool HVRT_DIAG_BUILD = false;
+#endif
 
-__device__ __forceinline__ int f2i(float f) {
-    return (!(f < 2147483648.0f) || f < -2147483648.0f) ? INT_MIN : (int)f;
-}
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // std::min / std::max as libstdc++ / MSVC define them (GeometryUtils.cpp:33-34 nests them).
@@ -81,6 +83,85 @@ __device__ __forceinline__ void ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, On
 
 // the mask of lanes for which b holds, straight from the compare (HIP's __ballot goes through an integer)
 __device__ __forceinline__ unsigned long long any_lane(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+
+// Selects on a lane mask held in a scalar register pair, in the VOP3 encoding.  Why by hand: for `c ? a : b` with c
+// the AND of two compares the compiler forms the mask with s_and_b64 into vcc and selects with the VOP2
+// v_cndmask_b32, and on gfx950 a VOP2 v_cndmask_b32 whose vcc was last written by the SCALAR unit blocks its SIMD for
+// ~19 clocks, however many waves are resident (scripts/ubench/valu_rate.hip: 19.5 clk for s_mov vcc + v_cndmask,
+// 6.1 for v_cmp vcc + v_cndmask, 4.0 for the VOP3 form with any mask).  The DDA step had one such select.
+typedef unsigned long long lanemask;
+__device__ __forceinline__ float sel(lanemask m, float if_set, float if_clear) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t sel(lanemask m, uint32_t if_set, uint32_t if_clear) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+    return r;
+}
+// static_cast<int> as the reference platform (x86 cvttss2si) does it: INT_MIN for NaN and out-of-range values
+// (v_cvt_i32_f32 saturates instead); the OR of the two compares is a scalar-unit mask, hence the VOP3 select
+__device__ __forceinline__ int f2i(float f) {
+    const lanemask bad = __builtin_amdgcn_ballot_w64(!(f < 2147483648.0f)) | __builtin_amdgcn_ballot_w64(f < -2147483648.0f);
+    return (int)sel(bad, 0x80000000u, (uint32_t)(int)f);
+}
+// v - 1 where the lane's bit is set (one VOP3 instruction; the borrow out goes nowhere)
+__device__ __forceinline__ int dec_where(lanemask m, int v) {
+    lanemask borrow;
+    asm("v_subbrev_co_u32_e64 %0, %1, 0, %0, %2" : "+v"(v), "=s"(borrow) : "s"(m));
+    return v;
+}
+// advanceToNextVoxel (:201-260) on explicit lane masks.  cxy picks the x-or-y candidate, c2 compares that candidate
+// with z: the nested ifs of :204-259 (ties and NaNs fall to the else arms exactly as written there).
+#define HVRT_STEP()                                                             \
+    do {                                                                        \
+        const lanemask cxy = any_lane(tmx < tmy);                               \
+        const lanemask c2 = any_lane(sel(cxy, tmx, tmy) < tmz);                 \
+        const lanemask stx = cxy & c2, sty = c2 & ~cxy;                         \
+        tmx = sel(stx, tmx + tdx, tmx);                                         \
+        tmy = sel(sty, tmy + tdy, tmy);                                         \
+        tmz = sel(c2, tmz, tmz + tdz);                                          \
+        rx = dec_where(stx, rx); ry = dec_where(sty, ry);                       \
+        last = sel(c2, sel(cxy, fsx, fsy), fsz);                                \
+        f += last;                                                              \
+    } while (0)
+
+// A run of k empty-space steps during which one axis (the "far" one, C) is known not to step: the other two (A
+// before B in x, y, z order) then advance by `tmA < tmB ? A : B` alone -- a compare, two adds, two selects on the
+// compare's own vcc and a borrow, a third of the general step's instruction time.  Which of the reference's nested
+// compares (:204-259) that is, per far axis:
+//   z far: `(tmx < tmy ? tmx : tmy) < tmz` holds at every step  -> step x or y by tmx < tmy           (A = x, B = y)
+//   y far: `tmx < tmy` holds at every step                       -> step x or z by tmx < tmz           (A = x, B = z)
+//   x far: `tmx < tmy` fails at every step                       -> step y or z by tmy < tmz           (A = y, B = z)
+// The values compared only grow along a run (tDelta >= 0; a NaN fails every check), so each condition holds at
+// every step of the run iff it holds at the LAST step, which `OK` tests on the values that step compared (preA,
+// preB, c).  The run is speculative: the caller picks the far axis from a cheap estimate, OK decides exactly; when it
+// fails for any lane the state is rolled back and the general steps are taken.  On success the flat index and
+// the counters are brought up to date from the number of A steps (only rA is kept per step).
+#define HVRT_TWO_AXIS_RUN(tmA, tdA, rA, fsA, tmB, tdB, fsB, OK, AFTER)                               \
+    do {                                                                                             \
+        const float saveA = tmA, saveB = tmB;                                                        \
+        const int save_rA = rA;                                                                      \
+        for (int i = 1; i < k; ++i) {                                                                \
+            const bool c = tmA < tmB;                                                                \
+            const float na = tmA + tdA, nb = tmB + tdB;                                              \
+            tmA = c ? na : tmA; tmB = c ? tmB : nb; rA -= c ? 1 : 0;                                 \
+        }                                                                                            \
+        const float preA = tmA, preB = tmB;                                                          \
+        const bool c = tmA < tmB;                                                                    \
+        { const float na = tmA + tdA, nb = tmB + tdB; tmA = c ? na : tmA; tmB = c ? tmB : nb; rA -= c ? 1 : 0; } \
+        (void)preA; (void)preB;                                                                      \
+        if (any_lane(!(OK)) == 0ull) {                                                               \
+            const uint32_t dA = (uint32_t)(save_rA - rA), dB = (uint32_t)k - dA;                     \
+            f += dA * fsA + dB * fsB;                                                                \
+            last = c ? fsA : fsB;                                                                    \
+            AFTER;                                                                                   \
+            ran = true;                                                                              \
+        } else {                                                                                     \
+            tmA = saveA; tmB = saveB; rA = save_rA;                                                  \
+        }                                                                                            \
+    } while (0)
 
 struct TraceResult {
     uint32_t tri;   // HVRT_MISS when nothing was hit
@@ -170,19 +251,6 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
     if (COUNT) r.nv = 1;
 #endif
 
-    // cxy picks the x-or-y candidate, c2 compares that candidate with z: the nested ifs of :204-259
-#define HVRT_STEP()                                                             \
-    do {                                                                        \
-        const bool cxy = tmx < tmy;                                             \
-        const bool c2 = (cxy ? tmx : tmy) < tmz;                                \
-        const bool stx = cxy && c2, sty = !cxy && c2;                           \
-        tmx = stx ? tmx + tdx : tmx;                                            \
-        tmy = sty ? tmy + tdy : tmy;                                            \
-        tmz = c2 ? tmz : tmz + tdz;                                             \
-        rx -= stx ? 1 : 0; ry -= sty ? 1 : 0;                                   \
-        last = c2 ? (cxy ? fsx : fsy) : fsz;                                    \
-        f += last;                                                              \
-    } while (0)
     // the steps-left counters only ever decrease: once one is negative the ray has left the grid for good
 #define HVRT_IN_GRID() ((rx | ry | (zsum - tot - rx - ry)) >= 0)
     // nearest-hit mode: is the kept hit at or before the exit of the current voxel (the tMax the next step takes)?
@@ -254,7 +322,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
         // a surviving x step implies nx > 1 (it would have left a 1-wide grid), so fsx, fsy, fsz are told
         // apart by testing the axes in this order with their extent
         const bool entered = last != 0u;          // false: the ray's first voxel, nothing was tested before
-        const uint32_t face = (last == fsx && g.nx > 1) ? facex : (last == fsy && g.ny > 1) ? facey : facez;
+        const uint32_t face = sel(any_lane(last == fsx) & (g.nx > 1 ? ~0ull : 0ull), facex, sel(any_lane(last == fsy) & (g.ny > 1 ? ~0ull : 0ull), facey, facez));
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         uint32_t bkey = 0;   // RAYS < 64: 1 + list position of this slice's candidate, 0 = none from this list
         {
@@ -342,7 +410,6 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
 #endif
     }
 #undef HVRT_IN_GRID
-#undef HVRT_STEP
 #undef HVRT_NEAREST_DONE
 #undef HVRT_LOAD_VOXEL
     return r;
@@ -386,6 +453,9 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
     const int lane = (int)(threadIdx.x & 63u);
     TraceResult r;
     r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
+#if defined(HVRT_ABLATE) && HVRT_ABLATE >= 3      // 3 = no walk: what a tile costs before and after its rays (4: and no pixel stores, 5: and no duration store, 6: and no ray set-up)
+    alive = false;
+#endif
 
     V3 st = o;
     if (NEAREST) {
@@ -403,7 +473,10 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
     const int iy = clampi(f2i((st.y - g.mny) / g.vsy), 0, g.ny - 1);
     const int iz = clampi(f2i((st.z - g.mnz) / g.vsz), 0, g.nz - 1);
     const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;
-    const float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
+    float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
+    // (the absolute values are taken here, once: left to the compiler they become |x| source modifiers on every
+    // `tMax + tDelta` of the walk, which forces those adds into the VOP3 encoding -- 4 clocks of issue instead of 2)
+    asm volatile("" : "+v"(tdx), "+v"(tdy), "+v"(tdz));
     float tmx = ((g.mnx + (float)(px ? ix + 1 : ix) * g.vsx) - o.x) / d.x;
     float tmy = ((g.mny + (float)(py ? iy + 1 : iy) * g.vsy) - o.y) / d.y;
     float tmz = ((g.mnz + (float)(pz ? iz + 1 : iz) * g.vsz) - o.z) / d.z;
@@ -424,18 +497,6 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
     if (COUNT) r.nv = alive ? 1u : 0u;
 #endif
 
-#define HVRT_STEP()                                                             \
-    do {                                                                        \
-        const bool cxy = tmx < tmy;                                             \
-        const bool c2 = (cxy ? tmx : tmy) < tmz;                                \
-        const bool stx = cxy && c2, sty = !cxy && c2;                           \
-        tmx = stx ? tmx + tdx : tmx;                                            \
-        tmy = sty ? tmy + tdy : tmy;                                            \
-        tmz = c2 ? tmz : tmz + tdz;                                             \
-        rx -= stx ? 1 : 0; ry -= sty ? 1 : 0;                                   \
-        last = c2 ? (cxy ? fsx : fsy) : fsz;                                    \
-        f += last;                                                              \
-    } while (0)
 #define HVRT_IN_GRID() ((rx | ry | (zsum - tot - rx - ry)) >= 0)
 #define HVRT_NEAREST_DONE()                                                     \
     (r.tri != HVRT_MISS && r.t <= (((tmx < tmy ? tmx : tmy) < tmz) ? (tmx < tmy ? tmx : tmy) : tmz))
@@ -463,7 +524,7 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 }
             }
             if (search) {
-                if (COUNT || NEAREST) {
+                if ((COUNT && !HVRT_DIAG_BUILD) || NEAREST) {      // (a diagnostic build counts other things)
                     bool going = true;
                     for (int i = 0; i < k; ++i) {
                         if (NEAREST) { done = done || HVRT_NEAREST_DONE(); going = going && !done; }
@@ -476,7 +537,25 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                     }
                     search = going;
                 } else {
-                    for (int i = 0; i < k; ++i) HVRT_STEP();
+                    bool ran = false;
+                    if (k >= 4) {
+                        // which axis, if any, stays out of this run for every lane?  (estimates; the run itself checks)
+                        const float kf = (float)k;
+                        const float ex = tmx + kf * tdx, ey = tmy + kf * tdy;
+                        if (any_lane(!(ex < tmz && ey < tmz)) == 0ull)
+                            HVRT_TWO_AXIS_RUN(tmx, tdx, rx, fsx, tmy, tdy, fsy, (c ? preA : preB) < tmz, ry -= (int)dB);
+                        else if (any_lane(!(ex < tmy)) == 0ull)
+                            HVRT_TWO_AXIS_RUN(tmx, tdx, rx, fsx, tmz, tdz, fsz, preA < tmy, (void)0);
+                        else if (any_lane(tmx < ey) == 0ull)
+                            HVRT_TWO_AXIS_RUN(tmy, tdy, ry, fsy, tmz, tdz, fsz, !(tmx < preA), (void)0);
+                    }
+#if defined(HVRT_DIAG) && HVRT_DIAG == 21   // steps of two-axis runs | general steps of runs with k >= 4
+                    if (ran) r.nv += (uint32_t)k; else if (k >= 4) r.nt += (uint32_t)k;
+#elif defined(HVRT_DIAG) && HVRT_DIAG == 22   // general steps of runs with k < 4 | runs (consults that stepped)
+                    if (k < 4) r.nv += (uint32_t)k;
+                    r.nt += 1;
+#endif
+                    if (!ran) for (int i = 0; i < k; ++i) HVRT_STEP();
                     tot += k;
                     search = HVRT_IN_GRID();
                 }
@@ -486,9 +565,11 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         alive = alive && HVRT_IN_GRID();
         if (any_lane(alive) == 0ull) break;
         uint32_t b0 = 0, b1 = 0;
+#if !defined(HVRT_ABLATE) || HVRT_ABLATE < 2      // ablation builds (timing experiments only): 2 = no lists at all
         if (alive) { const uint32_t* pv = offs + f; b0 = pv[0]; b1 = pv[1]; }
+#endif
         const bool entered = last != 0u;
-        const uint32_t face = (last == fsx && g.nx > 1) ? facex : (last == fsy && g.ny > 1) ? facey : facez;
+        const uint32_t face = sel(any_lane(last == fsx) & (g.nx > 1 ? ~0ull : 0ull), facex, sel(any_lane(last == fsy) & (g.ny > 1 ? ~0ull : 0ull), facey, facez));
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         const uint32_t n = b1 - b0;       // 0 for lanes without a ray
         uint32_t c = 0;
@@ -528,6 +609,9 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 if (COUNT && HVRT_DIAG == 13) r.nt += (uint32_t)__builtin_popcount(todo);   // tests the lanes wanted
 #endif
                 win[lane] = A;
+#if defined(HVRT_ABLATE) && HVRT_ABLATE == 1      // 1 = lists fetched, no entry tested
+                um = 0;
+#endif
                 if (work) {
                     while (um) {
                         const int k = __builtin_ctz(um);
@@ -576,7 +660,6 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         if (any_lane(alive) == 0ull) break;
     }
 #undef HVRT_IN_GRID
-#undef HVRT_STEP
 #undef HVRT_NEAREST_DONE
     return r;
 }
@@ -663,7 +746,10 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
 // ABORT: the variant for launches without tile history (see "gives up" below); launches with history run the
 // plain one -- the bookkeeping costs 4 % of a config 2 frame, and history already sends long tiles elsewhere.
 template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) void k_render(SceneDev sc, RenderArgs ra) {
+#ifndef HVRT_RENDER_WAVES
+#define HVRT_RENDER_WAVES 7
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render(SceneDev sc, RenderArgs ra) {
     __shared__ float4 lds_win[4][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
     const int lane = threadIdx.x & 63;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
@@ -675,33 +761,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
     uint64_t tot_nv = 0, tot_nt = 0;
     unsigned long long wave_cost = 0;     // wave-uniform
     uint32_t given_up = 0xFFFFFFFFu;      // wave-uniform: the tile the previous iteration gave up on (see below)
+    // The queue head is ONE word, and one word takes about 88 returning atomics per microsecond from the whole chip
+    // (MI355X_MICROARCH.md, "dequeue"): 129 600 single-tile pulls cannot finish in under 1.5 ms, whatever the tiles
+    // cost -- a 4K frame of config 2 was bound by exactly that (a build whose rays do not walk at all took the
+    // same 1.77 ms).  So a wave pulls `batch` consecutive slots per atomic and sizes the next batch from what the last
+    // one cost per tile: about PULL_CLOCKS of work per pull (7000 waves then stay well under the word's rate), one
+    // tile at a time where tiles are long (the head of an ordered queue, the silhouette, supersampled frames),
+    // and never more than the waves' even share of what is left of the queue, so that the launch does not end on a
+    // wave with a full batch in hand.
+    constexpr long long PULL_CLOCKS = 400000;
+    constexpr uint32_t MAX_BATCH = 8;
+    uint32_t batch = 1, slot = 0, slot_end = 0;     // wave-uniform
+    long long batch_clk0 = 0;
+    const uint32_t n_waves = gridDim.x * 4u;
 
     for (;;) {
+        if (ABORT && lane == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
+        given_up = 0xFFFFFFFFu;
+        if (slot == slot_end) {
+            uint32_t got = 0;
+#if defined(HVRT_DIAG) && HVRT_DIAG == 31       // clocks spent waiting for the queue head | clocks in the loop, per wave
+            const long long pull0 = clock64();
+#endif
+            if (lane == 0) got = atomicAdd(ra.tile_counter, batch);
+            slot = (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
+#if defined(HVRT_DIAG) && HVRT_DIAG == 31
+            if (COUNT && lane == 0) { tot_nv += (uint64_t)(clock64() - pull0); tot_nt += 1; }
+#endif
+            if (slot >= n_queue) break;
+            slot_end = slot + batch < n_queue ? slot + batch : n_queue;
+            batch_clk0 = clock64();
+        }
         uint32_t pulled = 0;
         if (lane == 0) {
-            if (ABORT && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
-            pulled = atomicAdd(ra.tile_counter, 1u);
-            if (pulled >= n_queue) {
-                pulled = 0xFFFFFFFFu;
+            if (ra.order) {
+                pulled = ra.order[slot];
             } else {
-                if (ra.order) {
-                    pulled = ra.order[pulled];
-                } else {
-                    // no history for this shape yet: rows of tiles from the middle of the frame outwards.  The
-                    // reference's cameras look at the centre of the grid (TraceImages.cpp:125-197), so the
-                    // silhouette -- where the long tiles are -- surrounds the image centre and starts early.
-                    const uint32_t fi = pulled / tiles_frame, tf = pulled - fi * tiles_frame;
-                    const uint32_t q = tf / tiles_x, tx = tf - q * tiles_x;
-                    const uint32_t mid = tiles_y / 2, h = (q + 1) / 2;
-                    const uint32_t ty = (q & 1u) ? (mid >= h ? mid - h : tiles_y - 1 - (h - mid - 1))
-                                                 : (mid + h < tiles_y ? mid + h : (tiles_y - 1 - mid) + mid - h);
-                    pulled = fi * tiles_frame + ty * tiles_x + tx;
-                }
+                // no history for this shape yet: rows of tiles from the middle of the frame outwards.  The
+                // reference's cameras look at the centre of the grid (TraceImages.cpp:125-197), so the
+                // silhouette -- where the long tiles are -- surrounds the image centre and starts early.
+                const uint32_t fi = slot / tiles_frame, tf = slot - fi * tiles_frame;
+                const uint32_t q = tf / tiles_x, tx = tf - q * tiles_x;
+                const uint32_t mid = tiles_y / 2, h = (q + 1) / 2;
+                const uint32_t ty = (q & 1u) ? (mid >= h ? mid - h : tiles_y - 1 - (h - mid - 1))
+                                             : (mid + h < tiles_y ? mid + h : (tiles_y - 1 - mid) + mid - h);
+                pulled = fi * tiles_frame + ty * tiles_x + tx;
             }
         }
-        given_up = 0xFFFFFFFFu;
+        ++slot;
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)pulled, 0);   // wave-uniform (an SGPR)
-        if (tile >= n_tiles) break;
+        if (tile >= n_tiles) break;      // (never, with a well-formed order: every wave leaves through the queue's end)
         const long long clk0 = clock64();
         const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
         const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
@@ -720,8 +829,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
         const bool inside = x < ra.width && lr < ra.local_rows && y < ra.height;
         if constexpr (INLINE) {
             // wave-synchronous walk: lanes outside the image come along without a ray; giving up is wave-wide
+#if defined(HVRT_ABLATE) && HVRT_ABLATE >= 6
+            px.rgb = { 0.5f, 0.5f, (float)x }; px.hit = HVRT_MISS; px.t = FLT_MAX;
+#else
             gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, inside, lds_win[threadIdx.x >> 6], clk0, px);
+#endif
+#if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)
             if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr, x, px);
+#endif
         } else if (inside) {
             gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, true, nullptr, clk0, px);
             // the wave decides; a lane that finished its pixel holds its stores back until then
@@ -733,10 +848,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7))) voi
             const bool dropped = ABORT && any_lane(gave_up) != 0ull;
             const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
             const uint32_t dc = dt > 0x00FFFFFFull ? 0x00FFFFFFu : (uint32_t)dt;
+#if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 5 && HVRT_ABLATE != 7)
             ra.tile_cost[tile] = dc;      // a dropped tile: k_render_split adds its quads' durations to this
+#endif
             wave_cost += dc;
             if (dropped) given_up = tile;                       // appended to the list by the next iteration
+#if !defined(HVRT_DIAG) || HVRT_DIAG != 31
             else if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
+#endif
+        }
+        if (slot == slot_end) {
+            // size of the next pull: PULL_CLOCKS of work at this batch's cost per tile, halved while it exceeds the
+            // waves' even share of the slots that are left
+            const long long per_tile = (clock64() - batch_clk0) >> __builtin_ctz(batch);     // batch is 1, 2, 4 or 8
+            batch = per_tile * 4 > PULL_CLOCKS ? 1u : per_tile * 8 > PULL_CLOCKS ? 2u : per_tile * 16 > PULL_CLOCKS ? 4u : MAX_BATCH;
+            const uint32_t left = n_queue > slot_end ? n_queue - slot_end : 0u;
+            while (batch > 1u && batch * n_waves > left) batch >>= 1;
         }
     }
     if (ABORT && lane == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;

@@ -22,7 +22,9 @@ cam = capi.make_camera_frame(pos, la, up, fov, asp)
 cnt = ctx.render(cam, W, H)[3]
 n = W * H
 print(f"raw counters / rays: first {cnt[0]/n:.3f} second {cnt[1]/n:.3f}   (DIAG 11: cooperative | per-lane chunks per ray slot; "
-      f"12: cooperative | per-lane wave test iterations per ray slot; 13: cooperative iterations | tests the lanes wanted)")
+      f"12: cooperative | per-lane wave test iterations per ray slot; 13: cooperative iterations | tests the lanes wanted; "
+      f"21: steps in two-axis runs | general steps of runs with k >= 4; 22: general steps of runs with k < 4 | runs)")
+print(f"[DIAG=31: clocks waiting for the queue head in all {cnt[0]:.4g}, pulls {cnt[1]:.4g} -> {cnt[0]/max(cnt[1],1):.0f} clocks per pull]")
 print(f"[DIAG=2: second/first = share of wave iterations whose lanes all test one entry: {cnt[1]/max(cnt[0],1):.3f}]")
 print(f"tests executed per ray {cnt[1]/n:.2f}; wave test iterations per ray-slot {cnt[0]/n:.2f} (x64 lanes)")
 ctx.close()
