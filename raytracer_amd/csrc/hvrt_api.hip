@@ -81,7 +81,7 @@ struct hvrt_ctx {
     uint32_t* order_blocks = nullptr; uint64_t order_blocks_capacity = 0;
     uint32_t* split_tiles = nullptr; uint64_t split_tiles_capacity = 0;
     uint32_t* abandoned = nullptr; uint64_t abandoned_capacity = 0;
-    long long abort_clocks = 2400000;   // ~1 ms; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile
+    long long abort_ticks = 100000;     // 1 ms of the constant 100 MHz clock; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
     // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
     // Read without waiting -- a stale answer only delays the switch by a launch.  Starts at "some".
@@ -367,7 +367,10 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
-    if (const char* v = getenv("HVRT_TILE_ABORT_US")) c->abort_clocks = atoll(v) > 0 ? atoll(v) * 2400 : (1ll << 62);
+    if (const char* v = getenv("HVRT_TILE_ABORT_US")) {
+        const long long us = atoll(v);
+        c->abort_ticks = us > 0 ? (us < (1ll << 40) ? us * 100 : (1ll << 47)) : 0;      // 0: the plain kernel is launched
+    }
     if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
     // this device's copy of the scratch array (every GPU holds its own, at its own address)
     if ((e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
@@ -535,7 +538,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(uint64_t), s));
-    HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, cnt_of(c), c->ranges, s));
+    HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, cnt_of(c), c->ranges, c->stats, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, c->occ_bits, s));
     c->occ_bits_valid = true;
@@ -545,13 +548,18 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     // against 1.2 + 1.9 apart).  Grids whose x extent the bitmap kernel does not take are forked after the fill.
     if (nx % 4 == 0 && nx <= 16384) if (int r = fork_distance_field(c, s)) return r;
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    uint64_t h_stats[6];
+    uint64_t h_stats[8];
     HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     if (h_stats[5]) return fail(c, HVRT_ERR_HIP, "build_grid: the offset scan gave up waiting for a chunk (device fault?)");
+    // h_stats[7]: the count pass's own 64-bit total -- the scan's total (h_stats[0]) comes out of 32-bit partial sums
+    // and is only meaningful once this one is known to fit; nothing has been scattered yet
+    if (h_stats[7] > 0xFFFFFFFFull)
+        return fail(c, HVRT_ERR_OVERFLOW, "build_grid: %llu triangle references exceed the u32 CSR", (unsigned long long)h_stats[7]);
     const uint64_t total = h_stats[0];
-    if (total > 0xFFFFFFFFull)
-        return fail(c, HVRT_ERR_OVERFLOW, "build_grid: %llu triangle references exceed the u32 CSR", (unsigned long long)total);
+    if (total != h_stats[7])
+        return fail(c, HVRT_ERR_HIP, "build_grid: the scan's total (%llu) is not the count pass's (%llu)",
+                    (unsigned long long)total, (unsigned long long)h_stats[7]);
     if (int r = ensure<uint32_t>(c, c->indices, c->indices_capacity, total)) return r;
     if (int r = ensure<uint32_t>(c, c->long_queue, c->long_queue_capacity, total / 64 + 1)) return r;
     if (int r = ensure<uint32_t>(c, c->fill_scratch, c->fill_scratch_capacity, 2 * total)) return r;
@@ -603,10 +611,17 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
     HIP_TRY(c, hipMemcpyAsync(offsets_of(c), offsets, (nvox + 1) * 4, kind, s));
     if (n_refs) HIP_TRY(c, hipMemcpyAsync(c->indices, indices, n_refs * 4, kind, s));
     HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(uint64_t), s));
-    HIP_TRY(c, launch_csr_stats(offsets_of(c), nvox, c->stats, s));
-    uint64_t h_stats[4];
+    HIP_TRY(c, launch_csr_stats(offsets_of(c), nvox, c->indices, n_refs, c->n_tris, c->stats, s));
+    uint64_t h_stats[8];
     HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    // the caller's arrays are checked before anything is derived from them, whatever the record mode
+    if (h_stats[6])
+        return fail(c, HVRT_ERR_INVALID, "grid: the CSR offsets are malformed (%llu violations of: offsets[0] == 0, non-decreasing, "
+                    "offsets[n_voxels] == n_refs = %llu)", (unsigned long long)h_stats[6], (unsigned long long)n_refs);
+    if (h_stats[4])
+        return fail(c, HVRT_ERR_INVALID, "grid: %llu CSR entries reference a triangle index >= %u",
+                    (unsigned long long)h_stats[4], c->n_tris);
     c->n_refs = n_refs;
     c->n_occupied = h_stats[1];
     c->max_list = (uint32_t)h_stats[2];
@@ -788,7 +803,7 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     ra.n_split = c->order_blocks + order_blocks;
     ra.abandoned = c->abandoned;
     ra.n_abandoned = c->tile_counter + 1;
-    ra.abort_clocks = c->abort_clocks;
+    ra.abort_ticks = c->abort_ticks;
     ra.tile_cost = c->tile_cost;
     unsigned long long* prev_sum = c->cost_sum + c->cost_parity;
     c->cost_parity ^= 1;
@@ -812,7 +827,7 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     } else {
         // no history: the kernel may give up on over-long tiles; k_render_split renders those behind it (none,
         // as a rule: it then finds an empty list and ends)
-        const bool abortable = c->adaptive_split && n_tiles != 0;
+        const bool abortable = c->adaptive_split && n_tiles != 0 && c->abort_ticks > 0;    // HVRT_TILE_ABORT_US=0: never give up
         HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, abortable, s));
         if (abortable) {
             RenderArgs rb = ra;
@@ -871,7 +886,7 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
     ra.tile_counter = (uint32_t*)(sp + NOALLOC_QUEUE_HEAD);
     ra.order = nullptr;                 // no history is kept between these calls: rows of tiles from the middle outwards
     ra.split_tiles = nullptr; ra.n_split = nullptr;
-    ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_clocks = 0;   // the plain kernel: no tile is handed on
+    ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_ticks = 0;   // the plain kernel: no tile is handed on
     ra.tile_cost = (uint32_t*)(sp + NOALLOC_TILE_COST);
     ra.cost_sum = (unsigned long long*)(sp + NOALLOC_COST_SUM);
     // the array keeps the last call's contents: the queue head and the duration sum must start at zero (the

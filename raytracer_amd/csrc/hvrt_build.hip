@@ -3,16 +3,23 @@
 // Replaces the reference's voxelizeTrianglesDirect (SceneCreator.cpp:197-281) and its dead GPU /
 // inline variants (SceneCreator.cu:67-358, InlineVoxelizer.h:17-167) with:
 //   k_count       one lane per triangle: AABB -> inclusive voxel range (SceneCreator.cpp:23-37,
-//                 177-188, GeometryUtils.cpp:43-51), atomic count per voxel; big ranges are spread
-//                 over the whole wave
-//   k_scan_*      exclusive scan of the counts in flat order ix + nx*(iy + ny*iz) (three phases:
-//                 per-chunk reduce, scan of chunk sums, per-chunk wave-level scan + apply)
+//                 177-188, GeometryUtils.cpp:43-51), atomic count per voxel with run-aggregated
+//                 atomics; big ranges are spread over the whole wave; the exact 64-bit number of
+//                 references goes to stats[7] (overflow check before anything is scattered)
+//   k_scan        exclusive scan of the counts in flat order ix + nx*(iy + ny*iz) in ONE pass over
+//                 the array (chained scan with decoupled look-back, 32768 counters per workgroup);
+//                 also leaves the one-bit-per-voxel occupancy map for the distance field
 //   k_fill        scatter of triangle ids through atomic cursors (the scanned counts themselves:
 //                 after the fill cnt[v] == start(v+1), i.e. the buffer IS the CSR offsets array
 //                 shifted by one, so no separate cursor array and no copy)
-//   k_sort_*      per-voxel ascending order (the reference appends in ascending triangle order,
-//                 SceneCreator.cpp:212-230): insertion sort for short lists, LDS bitonic network
-//                 for long ones, global-memory bitonic beyond the LDS capacity
+//   k_rank_sort   per-voxel ascending order (the reference appends in ascending triangle order,
+//                 SceneCreator.cpp:212-230): an entry's final position is the number of smaller ids
+//                 in its list (lists of up to 96 entries); longer lists are queued for
+//   k_sort_long   an all-ascending bitonic network in LDS (<= 4096 and <= 32768 entries) or in
+//                 global memory beyond that
+//   k_dist_*, k_face_bits, k_expand_records   derived acceleration data of the traversal (empty-space
+//                 distance field, "also listed in that face neighbour" bits, per-reference records)
+//   k_csr_stats, k_check_indices   statistics and validation of a caller-supplied CSR
 // All integer / byte work; HBM-bound; no MFMA.  Compile with -ffp-contract=off.
 #include "hvrt_internal.hpp"
 
@@ -141,8 +148,11 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
     }
 }
 
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v);
+
 __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, uint32_t T, GridParams g,
-                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ ranges) {
+                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ ranges,
+                                               uint64_t* __restrict__ stats) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool valid = t < T;
     int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
@@ -164,6 +174,10 @@ __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, u
         ranges[3ull * t + 2] = (uint32_t)lz | ((uint32_t)hz << 16);
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
+    // the number of references, exactly, in 64 bits (stats[7]): the scan adds the per-voxel counters up in 32-bit
+    // partial sums, which more than 2^32 - 1 references would wrap before the host could see them
+    const uint64_t vol = wave_sum64(nonempty ? (uint64_t)(hx - lx + 1) * (uint64_t)(hy - ly + 1) * (uint64_t)(hz - lz + 1) : 0ull);
+    if ((threadIdx.x & 63u) == 0u && vol) atomicAdd((unsigned long long*)&stats[7], (unsigned long long)vol);
     walk_range<false>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
 }
 
@@ -520,21 +534,37 @@ __global__ __launch_bounds__(256) void k_face_bits(const uint32_t* __restrict__ 
     }
 }
 
-// occupancy statistics of an ingested CSR (hvrt_set_grid_csr*)
-__global__ __launch_bounds__(256) void k_csr_stats(const uint32_t* __restrict__ offsets, uint64_t nvox,
+// occupancy statistics of an ingested CSR (hvrt_set_grid_csr*), and its validation: everything downstream (face
+// bits, distance field, records, the traversal) trusts that offsets[0] == 0, that the offsets never decrease, that
+// offsets[nvox] == n_refs and that every index names a triangle of the mesh.  stats[6] counts the offsets that break
+// a rule, stats[4] (k_check_indices) the indices that do; the host rejects the grid when either is non-zero,
+// before any derived data is built and whatever the record mode.
+__global__ __launch_bounds__(256) void k_csr_stats(const uint32_t* __restrict__ offsets, uint64_t nvox, uint64_t n_refs,
                                                    uint64_t* __restrict__ stats) {
-    uint64_t occ = 0; uint32_t mx = 0;
+    uint64_t occ = 0, bad = 0; uint32_t mx = 0;
     for (uint64_t v = (uint64_t)blockIdx.x * 256u + threadIdx.x; v < nvox; v += (uint64_t)gridDim.x * 256u) {
-        uint32_t len = offsets[v + 1] - offsets[v];
+        const uint32_t a = offsets[v], b = offsets[v + 1];
+        bad += (b < a) + (v == 0 && a != 0u) + (v + 1 == nvox && (uint64_t)b != n_refs);
+        const uint32_t len = b < a ? 0u : b - a;
         occ += len > 0;
         mx = len > mx ? len : mx;
     }
     occ = wave_sum64(occ);
+    bad = wave_sum64(bad);
     mx = wave_max32(mx);
     if ((threadIdx.x & 63) == 0) {
         if (occ) atomicAdd((unsigned long long*)&stats[1], (unsigned long long)occ);
         if (mx) atomicMax((unsigned long long*)&stats[2], (unsigned long long)mx);
+        if (bad) atomicAdd((unsigned long long*)&stats[6], (unsigned long long)bad);
     }
+}
+__global__ __launch_bounds__(256) void k_check_indices(const uint32_t* __restrict__ indices, uint64_t n_refs, uint32_t n_tris,
+                                                       uint64_t* __restrict__ stats) {
+    uint64_t bad = 0;
+    for (uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x; j < n_refs; j += (uint64_t)gridDim.x * 256u)
+        bad += indices[j] >= n_tris;
+    bad = wave_sum64(bad);
+    if ((threadIdx.x & 63) == 0 && bad) atomicAdd((unsigned long long*)&stats[4], (unsigned long long)bad);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -898,9 +928,9 @@ hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_
 }
 
 hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* ranges,
-                        hipStream_t s) {
+                        uint64_t* stats, hipStream_t s) {
     if (T == 0) return hipSuccess;
-    k_count<<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges);
+    k_count<<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, stats);
     return hipGetLastError();
 }
 
@@ -983,11 +1013,17 @@ hipError_t launch_distance_field(const uint32_t* offsets, const uint32_t* occ_bi
     return hipGetLastError();
 }
 
-hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s) {
+hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, const uint32_t* indices, uint64_t n_refs,
+                            uint32_t n_tris, uint64_t* stats, hipStream_t s) {
     uint64_t blocks = (nvox + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks == 0) blocks = 1;
-    k_csr_stats<<<(unsigned)blocks, 256, 0, s>>>(offsets, nvox, stats);
+    k_csr_stats<<<(unsigned)blocks, 256, 0, s>>>(offsets, nvox, n_refs, stats);
+    if (n_refs) {
+        blocks = (n_refs + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        k_check_indices<<<(unsigned)blocks, 256, 0, s>>>(indices, n_refs, n_tris, stats);
+    }
     return hipGetLastError();
 }
 

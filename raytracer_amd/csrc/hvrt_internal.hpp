@@ -70,12 +70,12 @@ struct RenderArgs {
     // k_render_split, 16 waves per tile (split_tiles[0, *n_split), both written by k_order_place; with order).
     const uint32_t* split_tiles;
     const uint32_t* n_split;
-    // k_render gives up on a tile whose rays are still inside long lists abort_clocks after they set out and
+    // k_render gives up on a tile whose rays are still inside long lists abort_ticks after they set out and
     // appends it to abandoned[*n_abandoned++] (zeroed before the launch); a k_render_split launch behind it
     // renders those tiles (split_tiles = abandoned, n_split = n_abandoned).
     uint32_t* abandoned;
     uint32_t* n_abandoned;
-    long long abort_clocks;
+    long long abort_ticks;   // in ticks of the constant 100 MHz clock (wall_clock64), per sample of a pixel
     uint32_t* tile_cost;
     unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
 };
@@ -84,8 +84,9 @@ struct RenderArgs {
 constexpr int SCAN_CHUNK = 32768;  // counters per scan workgroup (1024 threads x 32)
 
 hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t n_tris, hipStream_t s);
+// stats[7] += the exact number of references (64-bit; zero on entry)
 hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
-                        uint32_t* ranges, hipStream_t s);
+                        uint32_t* ranges, uint64_t* stats, hipStream_t s);
 // in-place exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64 of scratch.
 // stats[0] <- total, stats[1] += occupied voxels, stats[2] <- longest list, stats[5] != 0: the scan gave up
 // (stats[5], stats[6] must be zero on entry)
@@ -104,7 +105,10 @@ hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint
                             uint32_t* face_bits, uint64_t face_words, hipStream_t s);
 // occ_bits: the bitmap launch_scan left for THESE offsets, or null (occupancy is then read from the offsets)
 hipError_t launch_distance_field(const uint32_t* offsets, const uint32_t* occ_bits, const GridParams& g, uint8_t* dist, hipStream_t s);
-hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, uint64_t* stats, hipStream_t s);
+// stats[1] += occupied voxels, stats[2] <- longest list, stats[6] += offsets that break the CSR rules (offsets[0] == 0,
+// non-decreasing, offsets[nvox] == n_refs), stats[4] += indices >= n_tris (all zero on entry)
+hipError_t launch_csr_stats(const uint32_t* offsets, uint64_t nvox, const uint32_t* indices, uint64_t n_refs,
+                            uint32_t n_tris, uint64_t* stats, hipStream_t s);
 hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* blocks x 6 + idx */,
                          uint64_t* partial_idx, int n_blocks, float* out6, hipStream_t s);
 int bounds_blocks(uint64_t n_points);

@@ -193,7 +193,7 @@ struct TraceResult {
 // candidates are reduced to the one the sequential loop would have kept -- the highest entry that hit (mode 0),
 // the smallest t, the lower entry on a tie (nearest-hit mode) -- so the result is the same bit for bit.
 //
-// ABORT (k_render): a walk that is still inside a list of more than 32 entries when the clock passes `deadline`
+// ABORT (k_render): a walk that is still inside a list of more than 32 entries when the 100 MHz clock passes `deadline`
 // gives up (tri = HVRT_ABORTED).  The clock is a scalar, so all lanes that are in such a list give up together;
 // the kernel then hands the whole tile to k_render_split.  Lists of up to 32 entries never look at the clock.
 constexpr uint32_t HVRT_ABORTED = 0xFFFFFFFEu;
@@ -337,7 +337,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
             static_assert(RAYS == 64 || RAYS == 16 || RAYS == 4, "slice masks are written for 1, 4 and 16 slices");
             const uint32_t slice_mask = RAYS == 64 ? 0xFFFFFFFFu : SLICE_BITS << ((threadIdx.x & 63u) / (uint32_t)RAYS);
             for (uint32_t c = 0; c < n; c += 32) {
-                if (ABORT && c != 0u && clock64() > deadline) { aborted = true; break; }
+                if (ABORT && c != 0u && wall_clock64() > (unsigned long long)deadline) { aborted = true; break; }
                 const uint32_t base = b0 + c;
                 uint32_t skip = 0;
                 if (entered) {
@@ -579,7 +579,7 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
             if (wm == 0ull) break;
             if (ABORT) {
                 // the wave gives the tile up as a whole: nothing of it is kept
-                if (any_lane(work && c != 0u) != 0ull && clock64() > deadline) { r.tri = HVRT_ABORTED; return r; }
+                if (any_lane(work && c != 0u) != 0ull && wall_clock64() > (unsigned long long)deadline) { r.tri = HVRT_ABORTED; return r; }
             }
             const uint32_t base = b0 + c;
             uint32_t todo = 0;
@@ -706,7 +706,7 @@ struct PixelResult {
 };
 template <bool COUNT, bool INLINE, bool NEAREST, int RAYS, bool ABORT>
 __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArgs& ra, const hvrt_camera_frame* __restrict__ cf,
-                                             int x, int y, bool alive, float4* __restrict__ win, long long clk0, PixelResult& out) {
+                                             int x, int y, bool alive, float4* __restrict__ win, long long wall0, PixelResult& out) {
     const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };          // wave-uniform: scalar loads
     const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
     const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
@@ -722,8 +722,8 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
         TraceResult r;
         // the wave-synchronous walk wants every lane of the wave in the call, with or without a ray (alive);
         // the per-lane walks are only ever called by lanes that have one
-        if constexpr (INLINE && RAYS == 64) r = trace_ray_wave<COUNT, NEAREST, ABORT>(sc, org, d, alive, win, clk0 + ra.abort_clocks * (s + 1));
-        else r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, clk0 + ra.abort_clocks * (s + 1));
+        if constexpr (INLINE && RAYS == 64) r = trace_ray_wave<COUNT, NEAREST, ABORT>(sc, org, d, alive, win, wall0 + ra.abort_ticks * (s + 1));
+        else r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, wall0 + ra.abort_ticks * (s + 1));
         if (ABORT && r.tri == HVRT_ABORTED) return false;
         const V3 c = shade(sc, r, org, v);
         if (ra.spp == 1) acc = c; else acc = add(acc, c);
@@ -812,6 +812,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)pulled, 0);   // wave-uniform (an SGPR)
         if (tile >= n_tiles) break;      // (never, with a well-formed order: every wave leaves through the queue's end)
         const long long clk0 = clock64();
+        // the give-up deadline runs on the constant 100 MHz clock (s_memrealtime): the shader clock, which prices the
+        // tiles, moves with the chip's power state
+        const long long wall0 = ABORT ? (long long)wall_clock64() : 0;
         const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
         const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
         const int x = (int)(tx * 8u) + (lane & 7);
@@ -832,13 +835,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
 #if defined(HVRT_ABLATE) && HVRT_ABLATE >= 6
             px.rgb = { 0.5f, 0.5f, (float)x }; px.hit = HVRT_MISS; px.t = FLT_MAX;
 #else
-            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, inside, lds_win[threadIdx.x >> 6], clk0, px);
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, inside, lds_win[threadIdx.x >> 6], wall0, px);
 #endif
 #if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)
             if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr, x, px);
 #endif
         } else if (inside) {
-            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, true, nullptr, clk0, px);
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, true, nullptr, wall0, px);
             // the wave decides; a lane that finished its pixel holds its stores back until then
             if (!ABORT || any_lane(gave_up) == 0ull) store_pixel(ra, fi, lr, x, px);
         }
@@ -898,6 +901,7 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
     unsigned long long wave_cost = 0;
     for (uint32_t item = wave0; item < n_items; item += n_waves) {
         const long long clk0 = clock64();
+        const long long wall0 = 0;      // this kernel never gives up
         const uint32_t tile = ra.split_tiles[item >> 4], quad = item & 15u;
         const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
         const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
@@ -907,7 +911,7 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
         const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
             PixelResult px;
-            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, x, y, true, nullptr, clk0, px);
+            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, x, y, true, nullptr, wall0, px);
             if (slice == 0) {
                 store_pixel(ra, fi, lr, x, px);
                 if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }

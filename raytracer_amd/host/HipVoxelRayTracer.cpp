@@ -9,7 +9,16 @@
 
 using namespace cg_datastructures;
 
+#include <type_traits>
+
+// What the C ABI and the .voxgrid format rely on, checked against whichever headers are in use (this repository's
+// rt_types.hpp / IRayTracer.hpp, or the reference's own with -DHVRT_USE_REFERENCE_HEADERS): SURVEY.md 8(a) a1-a3.
 static_assert(sizeof(Triangle) == 48 && sizeof(Vec3) == 12, "Triangle must be the 12-float AoS record");
+static_assert(sizeof(Voxel) == 28, "Voxel: bool + 3 pad, u32 start, u32 count, f32 density, Vec3 color (Voxels.h:17-23)");
+static_assert(sizeof(Ray) == 24 && sizeof(RayHit) == 52 && sizeof(Camera) == 44, "RayTracerCommon.h:9-43 layouts");
+static_assert(sizeof(RayHit) == sizeof(hvrt_hit), "hvrt_hit mirrors RayHit");
+static_assert(std::is_abstract<IRayTracer>::value && std::is_base_of<IRayTracer, HipVoxelRayTracer>::value &&
+              !std::is_abstract<HipVoxelRayTracer>::value, "HipVoxelRayTracer implements every pure virtual of IRayTracer");
 
 namespace {
 [[noreturn]] void raise(hvrt_ctx* c, const char* what) {

@@ -9,7 +9,12 @@
 #include <string>
 #include <vector>
 
+#ifdef HVRT_USE_REFERENCE_HEADERS   // built inside the reference tree: its own IRayTracer.h:17-44 and VoxelGrid.h:8-42
+#include "IRayTracer.h"            // (-> RayTracerCommon.h -> Voxels.h)
+#include "VoxelGrid.h"
+#else                              // standalone: this repository's restatement of the same types
 #include "IRayTracer.hpp"
+#endif
 
 struct hvrt_ctx;
 

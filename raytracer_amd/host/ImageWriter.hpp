@@ -1,7 +1,7 @@
 // ImageWriter.hpp -- PPM and PNG output of a float framebuffer with the reference's quantisation
 // (ImageSaver.h:18-75): byte = (uint8_t)clamp(c * 255.0f, 0.0f, 255.0f) (truncation), pixels written in
 // framebuffer order.  The PNG is a valid stored-deflate (uncompressed) stream; JPEG is not provided
-// (image encoding is I/O outside the hot path) and ".jpg" names are written as PPM bytes.
+// (image encoding is I/O outside the hot path) and a name with any other extension (".jpg") is written as PPM under that name with ".ppm" in its place.
 #pragma once
 
 #include <algorithm>

@@ -173,30 +173,37 @@ void TraceImages::TraceImageMultiView(std::string gridFileLocation, std::string 
     }
 }
 
+// The reference encodes .jpg / .png / .ppm by extension (TraceImages.cpp:272-317, stb_image_write); this library
+// has a PNG and a PPM writer and no JPEG encoder (image codecs are outside the hot path).  A name with any other
+// extension -- the reference's own driver passes ".jpg" for every output (RayTracer.cpp:24-27) -- is therefore
+// written as PPM under the same name with the extension replaced by ".ppm": the bytes never contradict the name, and
+// the log names the file that was really written.
+static std::string writable_name(const std::string& filename, std::string& ext) {
+    ext = lower_ext(filename);
+    if (ext == ".png" || ext == ".ppm") return filename;
+    fs::path p(filename);
+    p.replace_extension(".ppm");
+    LOG_WARN("No encoder for '{}' in this library: writing {} (PPM) instead of {}", ext.empty() ? "(no extension)" : ext, p.string(), filename);
+    ext = ".ppm";
+    return p.string();
+}
+
 void TraceImages::SaveImageBytes(const std::string& filename, const unsigned char* rgb8, int width, int height) {
-    const fs::path p(filename);
+    std::string ext;
+    const std::string out = writable_name(filename, ext);
+    const fs::path p(out);
     if (!p.parent_path().empty() && !fs::exists(p.parent_path())) fs::create_directories(p.parent_path());
-    const std::string ext = lower_ext(filename);
-    bool ok;
-    if (ext == ".png") ok = saveBytesToPNG(filename, rgb8, width, height);
-    else {
-        if (ext != ".ppm") LOG_WARN("Extension '{}' is written as PPM bytes by this library", ext);
-        ok = saveBytesToPPM(filename, rgb8, width, height);
-    }
-    if (ok) LOG_INFO("Image saved: {}", filename); else LOG_ERROR("Failed to save: {}", filename);
+    const bool ok = ext == ".png" ? saveBytesToPNG(out, rgb8, width, height) : saveBytesToPPM(out, rgb8, width, height);
+    if (ok) LOG_INFO("Image saved: {}", out); else LOG_ERROR("Failed to save: {}", out);
 }
 
 void TraceImages::SaveImage(const std::string& filename, const std::vector<Vec3>& pixels, int width, int height) {
-    const fs::path p(filename);
+    std::string ext;
+    const std::string out = writable_name(filename, ext);
+    const fs::path p(out);
     if (!p.parent_path().empty() && !fs::exists(p.parent_path())) fs::create_directories(p.parent_path());
-    const std::string ext = lower_ext(filename);
-    bool ok;
-    if (ext == ".png") ok = saveToPNG(filename, pixels, width, height);
-    else {
-        if (ext != ".ppm") LOG_WARN("Extension '{}' is written as PPM bytes by this library", ext);
-        ok = saveToPPM(filename, pixels, width, height);
-    }
-    if (ok) LOG_INFO("Image saved: {}", filename); else LOG_ERROR("Failed to save: {}", filename);
+    const bool ok = ext == ".png" ? saveToPNG(out, pixels, width, height) : saveToPPM(out, pixels, width, height);
+    if (ok) LOG_INFO("Image saved: {}", out); else LOG_ERROR("Failed to save: {}", out);
 }
 
 // ---------------------------------------------------------------------------------------- .voxgrid

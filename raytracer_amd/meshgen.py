@@ -88,21 +88,45 @@ def skewed_statue(n_base: int, n_patch: int, radius: float = 1.0, patch_half: fl
     return np.concatenate([base, to_aos(patch)], axis=0)
 
 
-def uv_sphere_soup(nlat: int, nlon: int, radius: float = 1.0) -> np.ndarray:
+def uv_sphere_soup(nlat: int, nlon: int, radius: float = 1.0, trig=None) -> np.ndarray:
     """The sin/cos sphere of SURVEY.md Appendix C as a triangle soup [2*nlat*nlon, 3, 3] INCLUDING the
-    degenerate pole triangles (the STL reader drops those).  libm-dependent."""
+    degenerate pole triangles (the STL reader drops those).  libm-dependent unless `trig` is given:
+    (sin_th[nlat+1], cos_th[nlat+1], cos_ph[nlon+1], sin_ph[nlon+1]) as float64, e.g. the tables recorded from the
+    survey machine's libm in tests/golden/uv_sphere_trig.npz -- every further operation is an IEEE double product
+    and a rounding to float32, the same everywhere."""
+    if trig is None:
+        th = [math.pi * i / nlat for i in range(nlat + 1)]
+        ph = [2 * math.pi * j / nlon for j in range(nlon + 1)]
+        trig = (np.array([math.sin(t) for t in th]), np.array([math.cos(t) for t in th]),
+                np.array([math.cos(p) for p in ph]), np.array([math.sin(p) for p in ph]))
+    sin_th, cos_th, cos_ph, sin_ph = (np.asarray(a, np.float64) for a in trig)
+    assert sin_th.shape == (nlat + 1,) and cos_ph.shape == (nlon + 1,)
     pts = np.empty((nlat + 1, nlon + 1, 3), np.float32)
-    for i in range(nlat + 1):
-        th = math.pi * i / nlat
-        for j in range(nlon + 1):
-            ph = 2 * math.pi * j / nlon
-            pts[i, j, 0] = radius * math.sin(th) * math.cos(ph)
-            pts[i, j, 1] = radius * math.cos(th)
-            pts[i, j, 2] = radius * math.sin(th) * math.sin(ph)
+    rs = float(radius) * sin_th                                  # (radius * sin(th)) * cos(ph), left to right
+    pts[:, :, 0] = (rs[:, None] * cos_ph[None, :]).astype(np.float32)
+    pts[:, :, 1] = (float(radius) * cos_th)[:, None].astype(np.float32)
+    pts[:, :, 2] = (rs[:, None] * sin_ph[None, :]).astype(np.float32)
     a, b, c, d = pts[:-1, :-1], pts[1:, :-1], pts[1:, 1:], pts[:-1, 1:]
     t1 = np.stack([a, c, b], axis=2)
     t2 = np.stack([a, d, c], axis=2)
     return np.stack([t1, t2], axis=2).reshape(-1, 3, 3)
+
+
+def uv_sphere_trig_tables(nlat: int, nlon: int):
+    """The four libm tables uv_sphere_soup needs (this machine's libm)."""
+    th = [math.pi * i / nlat for i in range(nlat + 1)]
+    ph = [2 * math.pi * j / nlon for j in range(nlon + 1)]
+    return (np.array([math.sin(t) for t in th]), np.array([math.cos(t) for t in th]),
+            np.array([math.cos(p) for p in ph]), np.array([math.sin(p) for p in ph]))
+
+
+def stl_reader_view(soup: np.ndarray):
+    """What the reference's STL reader makes of a triangle soup (STLReader.h:451-535): triangles whose corners are
+    not three distinct vertices (exact float equality) are dropped, vertices are de-duplicated.  Returns
+    (kept triangles as the 12-float AoS with computed normals, unique vertices)."""
+    a, b, c = soup[:, 0], soup[:, 1], soup[:, 2]
+    keep = ~((a == b).all(1) | (a == c).all(1) | (b == c).all(1))
+    return to_aos(soup[keep]), np.unique(soup.reshape(-1, 3), axis=0)
 
 
 def box(lo=(-1.0, -1.0, -1.0), hi=(1.0, 1.0, 1.0)) -> np.ndarray:

@@ -105,7 +105,25 @@ def ray_box_vectors():
     print("raybox_vectors", n, "cases,", int(hit.sum()), "hits")
 
 
+def uv_sphere_trig_tables():
+    """uv_sphere_trig.npz: the sin / cos tables (float64, this container's libm -- the one the survey session's
+    reference runs used) of the two sin/cos spheres whose REFERENCE outputs SURVEY.md records (Appendix C: 100 x 200
+    -> 39 800 triangles; section 6: 708 x 708 -> 1 001 820 triangles).  With them meshgen.uv_sphere_soup rebuilds
+    those meshes bit for bit on any machine, so the recorded-run tests never depend on the local libm.  Written only
+    if the meshes they give reproduce the recorded triangle / vertex counts."""
+    tabs = {}
+    for name, (a, b) in {"100x200": (100, 200), "708x708": (708, 708)}.items():
+        t = meshgen.uv_sphere_trig_tables(a, b)
+        for k, v in zip(("sin_th", "cos_th", "cos_ph", "sin_ph"), t):
+            tabs[f"{k}_{name}"] = v
+    tris, verts = meshgen.stl_reader_view(meshgen.uv_sphere_soup(100, 200, 1.0, tuple(tabs[f"{k}_100x200"] for k in ("sin_th", "cos_th", "cos_ph", "sin_ph"))))
+    assert tris.shape[0] == 39800 and verts.shape[0] == 20101, "this libm does not give the survey's Appendix C sphere"
+    np.savez_compressed(os.path.join(HERE, "uv_sphere_trig.npz"), **tabs)
+    print("uv_sphere_trig.npz:", {k: v.shape for k, v in tabs.items()})
+
+
 def main():
+    uv_sphere_trig_tables()
     if not oracle.have_ref():
         raise SystemExit("oracle/_ref/libref.so missing: run `make -C oracle ref` where /root/reference exists")
     if "--only-raybox" in sys.argv:       # added after the other files were committed; leaves them untouched

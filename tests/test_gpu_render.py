@@ -366,8 +366,9 @@ def test_render_requires_a_scene(ctx):
 
 
 def test_config2_full_size_render_rows(ctx):
-    """BASELINE config 2 at full size (1 002 252 triangles, 256^3, 3840x2160): every 8th row compared
-    bit-for-bit with the oracle; all rows checked against frame-level properties."""
+    """BASELINE config 2 at full size (1 002 252 triangles, 256^3, 3840x2160): EVERY pixel of the frame compared
+    bit-for-bit with the oracle (hit id, t, colour; the oracle traces the 8.3 M rays in about a second on the
+    box's 16 host threads), then frame-level properties."""
     tris = meshgen.cube_sphere(289)
     ctx.set_mesh(tris)
     mn, mx = ctx.mesh_bounds()
@@ -379,7 +380,7 @@ def test_config2_full_size_render_rows(ctx):
     pos, la, up, fov, asp = capi.default_camera(mn, mx, aspect=W / H)
     fr = capi.make_camera_frame(pos, la, up, fov, asp)
     rgb, hit, t, cnt = render_both(ctx, fr, W, H)
-    rows = list(range(0, H, 8))
+    rows = list(range(H))
     ohit = np.zeros((len(rows), W), np.uint32)
     ot = np.zeros((len(rows), W), np.float32)
     orgb = np.zeros((len(rows), W, 3), np.float32)
@@ -391,9 +392,10 @@ def test_config2_full_size_render_rows(ctx):
 
     with ThreadPoolExecutor(16) as ex:
         list(ex.map(band, range(len(rows))))
-    assert np.array_equal(hit[rows], ohit)
-    assert np.array_equal(t[rows].view(np.uint32), ot.view(np.uint32))
-    assert np.array_equal(rgb[rows].view(np.uint32), orgb.view(np.uint32))
+    assert int((hit == ohit).sum()) >= 0.9999 * W * H          # the bar north_star states ...
+    assert np.array_equal(hit, ohit)                            # ... and what is actually met: every pixel
+    assert np.array_equal(t.view(np.uint32), ot.view(np.uint32))
+    assert np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32))
     # properties over the whole frame
     m = hit != MISS
     assert 0.03 < m.mean() < 0.10
@@ -503,3 +505,59 @@ def test_ingested_grid_with_unsorted_or_foreign_lists(ctx):
     bad[5] = tris.shape[0] + 7
     with pytest.raises(capi.HvrtError):
         ctx.set_grid_csr(20, 20, 20, mn, mx, vs, noff, bad)
+
+
+@pytest.mark.parametrize("inline_records", ["1", "0"])
+def test_ingested_csr_is_validated_in_both_record_modes(monkeypatch, inline_records):
+    """hvrt_set_grid_csr(_device) checks the caller's arrays before anything is derived from them -- offsets[0] == 0,
+    offsets never decrease, offsets[n_voxels] == n_refs, every index < n_tris -- with per-reference records
+    (HVRT_INLINE_RECORDS=1, the default) and in the indexed mode (=0), whose traversal reads tri_rec[index] directly.
+    The indexed mode's frames are the oracle's too (it runs the per-lane walk, not the wave-synchronous one)."""
+    import raytracer_amd as ra
+    import torch
+    monkeypatch.setenv("HVRT_INLINE_RECORDS", inline_records)
+    own = ra.Context(0)
+    try:
+        tris = meshgen.skewed_statue(12, 60)
+        sc, mn, mx, vs = oracle.build_scene(tris, 16, 16, 16)
+        own.set_mesh(tris)
+        own.set_grid_csr(16, 16, 16, mn, mx, vs, sc.offsets, sc.indices)
+        for view in ("front", "side"):
+            fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view))
+            assert_frames_equal(render_both(own, fr, 200, 150), sc.render(fr, 200, 150, threads=8))
+        o = np.array([[0.1, 0.2, -4.0], [3.0, 0.1, 0.2]], np.float32)
+        d = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0]], np.float32)
+        got, gcnt = own.trace(o, d)
+        exp, ecnt = sc.trace(o, d)
+        assert got.tobytes() == exp.tobytes() and np.array_equal(gcnt, ecnt)
+        # a grid built on the GPU in this mode renders the same frame
+        own.build_grid(16, 16, 16, mn, mx, vs)
+        fr = capi.make_camera_frame(*capi.default_camera(mn, mx))
+        assert_frames_equal(render_both(own, fr, 200, 150), sc.render(fr, 200, 150, threads=8))
+
+        def rejected(off, idx, match):
+            with pytest.raises(capi.HvrtError, match=match):
+                own.set_grid_csr(16, 16, 16, mn, mx, vs, off, idx)
+            with pytest.raises(capi.HvrtError):          # the failed call leaves the context without a grid
+                own.grid_info()
+
+        bad = sc.indices.copy(); bad[len(bad) // 2] = tris.shape[0]
+        rejected(sc.offsets, bad, "triangle index")
+        bad = sc.indices.copy(); bad[-1] = 0xFFFFFFFF
+        rejected(sc.offsets, bad, "triangle index")
+        occupied = np.flatnonzero(np.diff(sc.offsets.astype(np.int64)) > 0)
+        off = sc.offsets.copy(); off[occupied[3] + 1] = off[occupied[3]] - 1 if off[occupied[3]] else 0xFFFFFFF0
+        off[-1] = sc.offsets[-1]
+        rejected(off, sc.indices, "offsets are malformed")
+        off = sc.offsets.copy(); off[0] = 1
+        rejected(off, sc.indices, "offsets are malformed")
+        # device form: n_refs comes from the caller and must be offsets[n_voxels]
+        d_off = torch.from_numpy(sc.offsets.view(np.int32)).to("cuda:0")
+        d_idx = torch.from_numpy(sc.indices.view(np.int32)).to("cuda:0")
+        torch.cuda.synchronize()
+        with pytest.raises(capi.HvrtError, match="offsets are malformed"):
+            own.set_grid_csr_device(16, 16, 16, mn, mx, vs, d_off.data_ptr(), d_idx.data_ptr(), int(sc.offsets[-1]) - 1)
+        own.set_grid_csr_device(16, 16, 16, mn, mx, vs, d_off.data_ptr(), d_idx.data_ptr(), int(sc.offsets[-1]))
+        assert_frames_equal(render_both(own, fr, 200, 150), sc.render(fr, 200, 150, threads=8))
+    finally:
+        own.close()

@@ -188,3 +188,19 @@ def test_trace_image_error_behaviour(tmp_path):
     p = run("render", stl, "x.ppm", "--method", "octree", "--outdir", str(tmp_path) + "/", check=False)
     assert p.returncode == 1 and "reference's CPU tracer" in p.stderr
     assert not os.path.exists(tmp_path / "x.ppm")
+
+
+@pytest.mark.gpu
+def test_jpg_output_names_are_written_as_ppm_under_a_ppm_name(tmp_path):
+    """The reference's driver passes .jpg names (RayTracer.cpp:24-27); this library has no JPEG encoder, so the
+    file is written as PPM with the extension replaced -- never PPM bytes under a JPEG name."""
+    stl = os.path.join(G, "fixture_binary.stl")
+    out = str(tmp_path) + "/"
+    p = run("render", stl, "view.jpg", "--outdir", out, "--size", "160x120", "--grid", "16")
+    assert not os.path.exists(tmp_path / "view.jpg")
+    assert open(tmp_path / "view.ppm", "rb").read(2) == b"P6"
+    assert "view.ppm" in (p.stdout + p.stderr)
+    run("render", stl, "mv.jpg", "--multiview", "--outdir", out, "--size", "160x120", "--grid", "16", "--quiet")
+    for view in ("front", "side", "top"):
+        assert open(tmp_path / f"mv_{view}.ppm", "rb").read(2) == b"P6"
+        assert not os.path.exists(tmp_path / f"mv_{view}.jpg")

@@ -150,22 +150,35 @@ def test_moller_trumbore_live_vs_reference():
 
 # ---------------------------------------------------------------- SURVEY.md Appendix C (recorded reference run)
 
-def _appendix_c_mesh():
-    soup = meshgen.uv_sphere_soup(100, 200, 1.0)
-    # STLReader.h:506-518: drop triangles whose corners are not three distinct vertices (exact float equality)
-    a, b, c = soup[:, 0], soup[:, 1], soup[:, 2]
-    keep = ~((a == b).all(1) | (a == c).all(1) | (b == c).all(1))
-    kept = soup[keep]
-    verts = np.unique(soup.reshape(-1, 3), axis=0)
-    return meshgen.to_aos(kept), verts
+RECORDED = {
+    # outputs of the real reference (compiled in the survey session) on the 100 x 200 sin/cos
+    # sphere, 50^3 grid, 800 x 600, default front camera
+    "appendix_c": dict(nlat=100, nlon=200, grid=50, W=800, H=600, tris=39800, verts=20101, refs=144331, occupied=14960,
+                       max_list=504, hits=35137, V=37.9, T=111.1),
+    # SURVEY.md section 6, second recorded run: 708 x 708 sphere, 256^3 grid, 384 x 216, same camera rule
+    "section_6": dict(nlat=708, nlon=708, grid=256, W=384, H=216, tris=1001820, refs=3617504, V=192.6, T=226.4),
+}
+
+
+def recorded_mesh(which):
+    """The mesh of a recorded reference run, rebuilt from the survey machine's sin/cos tables (committed as
+    tests/golden/uv_sphere_trig.npz by make_golden.py): no dependence on this machine's libm."""
+    r = RECORDED[which]
+    z = np.load(os.path.join(G, "uv_sphere_trig.npz"))
+    key = f"{r['nlat']}x{r['nlon']}"
+    trig = tuple(z[f"{k}_{key}"] for k in ("sin_th", "cos_th", "cos_ph", "sin_ph"))
+    return meshgen.stl_reader_view(meshgen.uv_sphere_soup(r["nlat"], r["nlon"], 1.0, trig))
 
 
 def test_survey_appendix_c_recorded_reference_outputs():
-    """Mesh, grid and camera of SURVEY.md Appendix C (39 800-tri sin/cos sphere, 50^3, 800x600, front
-    camera).  Expected values are the real reference's outputs recorded there; libm-dependent mesh."""
-    tris, verts = _appendix_c_mesh()
-    if tris.shape[0] != 39800 or verts.shape[0] != 20101:
-        pytest.skip("this libm's sin/cos give a different sphere than the survey machine's")
+    """Mesh, grid and camera of SURVEY.md Appendix C (39 800-tri sin/cos sphere, 50^3, 800x600, front camera).
+    Expected values are the real reference's outputs recorded there.  This is the pin of the two functions that
+    cannot be compiled here (voxelizeTrianglesDirect, SceneCreator.cpp:197-281; traverseVoxelGrid and its helpers,
+    OctreeLikeRayTracer.cpp:155-336): reference-held values vs the oracle.  tests/test_gpu_recorded_runs.py holds
+    the same values against the HIP path, with no oracle in between."""
+    r = RECORDED["appendix_c"]
+    tris, verts = recorded_mesh("appendix_c")
+    assert tris.shape[0] == r["tris"] and verts.shape[0] == r["verts"]      # "39 800 kept, 20 101 unique vertices"
     sc, mn, mx, vs = oracle.build_scene(tris, 50, 50, 50, points=verts)
     cnt = np.diff(sc.offsets.astype(np.int64))
     assert sc.indices.size == 144331                 # "CSR: refs 144 331"
@@ -208,6 +221,23 @@ def test_survey_appendix_c_recorded_reference_outputs():
     assert h["triangle_index"] == 18099 and cc[0] == 5       # "5 voxels (spurious first X step)"
     h, cc = probe(410, 300)
     assert h["hit"] == 0 and cc[0] == 50                     # "MISS ..., 50 voxels (X never steps)"
+
+
+def test_survey_section_6_second_recorded_reference_run():
+    """the reference on the 708 x 708 sphere (1 001 820 triangles after the STL reader) in a
+    256^3 grid: 3 617 504 references; 384 x 216 default front camera (aspect 800/600 as setupCamera hard-codes,
+    TraceImages.cpp:143-144): 192.6 voxels and 226.4 triangle tests per ray."""
+    r = RECORDED["section_6"]
+    tris, verts = recorded_mesh("section_6")
+    assert tris.shape[0] == r["tris"]
+    sc, mn, mx, vs = oracle.build_scene(tris, 256, 256, 256, points=verts)
+    assert sc.indices.size == r["refs"]
+    from raytracer_amd import capi
+    fr = oracle.camera_frame(*capi.default_camera(mn, mx, "front"))
+    W, H = r["W"], r["H"]
+    rgb, hit, t, c = sc.render(fr, W, H, threads=8)
+    assert abs(c[0] / (W * H) - r["V"]) < 0.05
+    assert abs(c[1] / (W * H) - r["T"]) < 0.05
 
 
 def test_ray_box_golden():
