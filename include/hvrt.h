@@ -195,6 +195,12 @@ int hvrt_render(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int width, int he
                 int spp, uint32_t seed,
                 float* rgb, uint32_t* hit_id, float* t, uint64_t counters[2]);
 
+/* Replaces: the hit counter of OctreeLikeRayTracer::render (OctreeLikeRayTracer.cpp:106-111, logged by :57-65 as
+ * "Ray hits"): the number of pixels of the last hvrt_render / hvrt_render_views_rgb8 call whose (sample-0) ray hit a
+ * triangle, counted on the device -- so a caller that only wants the frame and the statistics need not fetch the
+ * hit-id image to count them. */
+int hvrt_last_hit_count(const hvrt_ctx* ctx, uint64_t* out);
+
 /* Device-resident form, and the multi-GPU partition: the image is cut into row tiles of tile_rows
  * rows; tile k belongs to part (k % n_parts).  This call renders the tiles of `part` into compact
  * device buffers holding hvrt_part_rows() rows of `width` pixels, in tile order.  n_parts == 1
@@ -254,7 +260,9 @@ int hvrt_render_views_rgb8(hvrt_ctx* ctx, const hvrt_camera_frame* frames, int n
 int hvrt_part_rows(int height, int tile_rows, int part, int n_parts);
 /* Reassembles a frame from gathered parts: d_parts holds n_parts slabs of slab_rows x width
  * pixels of bytes_per_pixel bytes each (slab_rows >= hvrt_part_rows of every part); writes
- * height x width pixels to d_frame.  Asynchronous on the context's stream. */
+ * height x width pixels to d_frame.  A row (width x bytes_per_pixel bytes) must be a whole number of
+ * 4-byte words: 12 (float rgb) and 4 (hit id, t) always are, 3 (the 8-bit rgb of hvrt_quantise_rgb8_device,
+ * which is what the multi-GPU exchange moves) when width is a multiple of 4.  Asynchronous on the context's stream. */
 int hvrt_assemble_parts_device(hvrt_ctx* ctx, const void* d_parts, int width, int height,
                                int tile_rows, int n_parts, int slab_rows, int bytes_per_pixel,
                                void* d_frame);

@@ -24,7 +24,7 @@ SYMBOLS = [
     "hvrt_set_mesh", "hvrt_set_mesh_device", "hvrt_compute_bounds", "hvrt_mesh_bounds", "hvrt_voxel_size",
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
-    "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc",
+    "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc", "hvrt_last_hit_count",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_render_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32,
                                             C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_render_part_device_noalloc.argtypes = lib.hvrt_render_part_device.argtypes
+    lib.hvrt_last_hit_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.hvrt_render_batch_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                                   C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_quantise_rgb8_device.argtypes = [vp, vp, C.c_uint64, vp]
@@ -305,6 +306,12 @@ class Context:
         self._ck(self._lib.hvrt_render(self._h, C.byref(frame), width, height, spp, seed,
                                        _ptr(rgb), _ptr(hit), _ptr(t), _ptr(cnt)))
         return rgb, hit, t, cnt
+
+    def last_hit_count(self) -> int:
+        """Pixels of the last render() / render_views_rgb8() whose ray hit a triangle (counted on the device)."""
+        n = C.c_uint64()
+        self._ck(self._lib.hvrt_last_hit_count(self._h, C.byref(n)))
+        return int(n.value)
 
     def render_part_device(self, frame: CameraFrame, width: int, height: int, spp: int, seed: int,
                            tile_rows: int, part: int, n_parts: int,

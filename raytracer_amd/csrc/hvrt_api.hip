@@ -11,7 +11,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace hvrt;
@@ -23,6 +25,8 @@ struct hvrt_ctx {
     hipStream_t own_stream = nullptr;
     hipStream_t aux_stream = nullptr;   // k_render_split runs here, beside k_render
     hipStream_t df_stream = nullptr;    // the distance field is built here (lowest priority), beside fill / order / records
+    hipStream_t copy_stream = nullptr;  // hvrt_render: the rows one launch completed go to the host here while the next launch traces
+    hipEvent_t ev_seg[8] = {};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dist_in_flight = false;
     hipEvent_t ev[10] = {};
@@ -97,10 +101,14 @@ struct hvrt_ctx {
     void* out_buf[3] = {};  uint64_t out_cap[3] = {};   // rgb / hit / t staging for host-facing render
     void* io_buf[3] = {};   uint64_t io_cap[3] = {};    // trace staging: origins / dirs / hits
 
-    // large downloads go through two pinned bounce buffers (pageable-memory copies run at a fraction of the link)
-    static constexpr size_t PIN_CHUNK = 8u << 20;
-    char* pin_buf[2] = {};
-    hipEvent_t pin_ev[2] = {};
+    // large downloads go through a ring of pinned bounce buffers (a DMA into pageable memory runs at a third of the
+    // link): 8 x 4 MiB, the DMA of chunk k + 8 queued as soon as copy thread (k mod 3) has emptied chunk k
+    // (scripts/ubench/host_xfer.hip: 6 GB/s plain, 17 GB/s with two 8-MiB buffers and one copying thread, 40 GB/s so)
+    static constexpr size_t PIN_CHUNK = 4u << 20;
+    static constexpr int PIN_RING = 8, PIN_THREADS = 3;
+    char* pin_ring = nullptr;
+    hipEvent_t pin_ev[PIN_RING] = {};
+    uint64_t last_hits = 0;        // hvrt_last_hit_count
 
     int mode = 0;   // hvrt_set_mode
 
@@ -177,30 +185,45 @@ int bind(hvrt_ctx* c) {
 }
 
 // Device -> caller's (pageable) host memory on stream s.  Small copies are issued directly and complete at the
-// caller's next stream synchronisation; large ones are pipelined through two pinned 8-MiB buffers -- the DMA of
-// chunk k overlaps the host memcpy of chunk k-1 -- and have completed on return.
+// caller's next stream synchronisation; large ones are pipelined through the context's ring of pinned chunks -- this
+// thread queues the DMAs, PIN_THREADS helper threads copy finished chunks out -- and have completed on return.
 int download(hvrt_ctx* c, void* dst, const void* src, uint64_t bytes, hipStream_t s) {
     if (bytes == 0) return HVRT_OK;
-    if (bytes < 4 * hvrt_ctx::PIN_CHUNK) {
+    constexpr uint64_t CH = hvrt_ctx::PIN_CHUNK;
+    constexpr int R = hvrt_ctx::PIN_RING, T = hvrt_ctx::PIN_THREADS;
+    if (bytes < 4 * CH || !c->pin_ring) {
         HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
         return HVRT_OK;
     }
-    for (int k = 0; k < 2; ++k) {
-        if (!c->pin_buf[k]) HIP_TRY(c, hipHostMalloc((void**)&c->pin_buf[k], hvrt_ctx::PIN_CHUNK, hipHostMallocDefault));
-        if (!c->pin_ev[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[k], hipEventDisableTiming));
-    }
-    const uint64_t n = (bytes + hvrt_ctx::PIN_CHUNK - 1) / hvrt_ctx::PIN_CHUNK;
-    auto size_of = [&](uint64_t k) { return k + 1 < n ? (uint64_t)hvrt_ctx::PIN_CHUNK : bytes - k * hvrt_ctx::PIN_CHUNK; };
-    for (uint64_t k = 0; k <= n; ++k) {
-        if (k < n) {
-            HIP_TRY(c, hipMemcpyAsync(c->pin_buf[k & 1], (const char*)src + k * hvrt_ctx::PIN_CHUNK, size_of(k), hipMemcpyDeviceToHost, s));
-            HIP_TRY(c, hipEventRecord(c->pin_ev[k & 1], s));
+    const uint64_t n = (bytes + CH - 1) / CH;
+    auto size_of = [&](uint64_t k) { return k + 1 < n ? CH : bytes - k * CH; };
+    std::vector<std::atomic<int>> issued(n), emptied(n);
+    for (uint64_t k = 0; k < n; ++k) { issued[k].store(0); emptied[k].store(0); }
+    std::atomic<int> failed{0};
+    const int device = c->device;
+    auto copier = [&](int t) {
+        (void)hipSetDevice(device);
+        for (uint64_t k = (uint64_t)t; k < n; k += T) {
+            while (!issued[k].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
+            if (hipEventSynchronize(c->pin_ev[k % R]) != hipSuccess) { failed.store(1); return; }
+            memcpy((char*)dst + k * CH, c->pin_ring + (k % R) * CH, size_of(k));
+            emptied[k].store(1, std::memory_order_release);
         }
-        if (k >= 1) {
-            HIP_TRY(c, hipEventSynchronize(c->pin_ev[(k - 1) & 1]));
-            memcpy((char*)dst + (k - 1) * hvrt_ctx::PIN_CHUNK, c->pin_buf[(k - 1) & 1], size_of(k - 1));
-        }
+    };
+    std::thread workers[T];
+    for (int t = 0; t < T; ++t) workers[t] = std::thread(copier, t);
+    hipError_t err = hipSuccess;
+    for (uint64_t k = 0; k < n && err == hipSuccess && !failed.load(); ++k) {
+        if (k >= (uint64_t)R)      // the ring slot is free once its previous chunk has been copied out
+            while (!emptied[k - R].load(std::memory_order_acquire)) { if (failed.load()) break; std::this_thread::yield(); }
+        err = hipMemcpyAsync(c->pin_ring + (k % R) * CH, (const char*)src + k * CH, size_of(k), hipMemcpyDeviceToHost, s);
+        if (err == hipSuccess) err = hipEventRecord(c->pin_ev[k % R], s);
+        if (err != hipSuccess) { failed.store(1); break; }
+        issued[k].store(1, std::memory_order_release);
     }
+    for (auto& w : workers) w.join();
+    if (err != hipSuccess || failed.load())
+        return fail(c, HVRT_ERR_HIP, "download: %s", err != hipSuccess ? hipGetErrorString(err) : "a copy thread failed waiting for its chunk");
     return HVRT_OK;
 }
 
@@ -349,6 +372,9 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
         if ((e = hipStreamCreateWithPriority(&c->df_stream, hipStreamNonBlocking, least)) != hipSuccess) return bail("hipStreamCreate", e);
     }
+    if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    for (auto& ev : c->ev_seg)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -358,7 +384,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipHostGetDevicePointer((void**)&c->split_hint_dev, c->split_hint, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc((void**)&c->stats, 8 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->stats, 72 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);   // 8 words + 64 striped totals
     if ((e = hipMalloc((void**)&c->tile_counter, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->cost_sum, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->cam_dev, sizeof(hvrt_camera_frame) * hvrt_ctx::CAM_SLOTS * hvrt_ctx::CAM_MAX)) != hipSuccess) return bail("hipMalloc", e);
@@ -372,6 +398,10 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         c->abort_ticks = us > 0 ? (us < (1ll << 40) ? us * 100 : (1ll << 47)) : 0;      // 0: the plain kernel is launched
     }
     if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
+    // the download ring belongs to the construction of a tracer, not to its first render()
+    if ((e = hipHostMalloc((void**)&c->pin_ring, hvrt_ctx::PIN_CHUNK * hvrt_ctx::PIN_RING, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    for (auto& ev : c->pin_ev)
+        if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     // this device's copy of the scratch array (every GPU holds its own, at its own address)
     if ((e = hipGetSymbolAddress((void**)&c->noalloc_scratch, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
@@ -387,6 +417,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->df_stream) (void)hipStreamSynchronize(c->df_stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
@@ -395,11 +426,13 @@ void hvrt_destroy(hvrt_ctx* c) {
     for (auto& ev : c->cam_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->cam_host) (void)hipHostFree(c->cam_host);
     if (c->split_hint) (void)hipHostFree(c->split_hint);
-    for (auto& b : c->pin_buf) if (b) (void)hipHostFree(b);
+    if (c->pin_ring) (void)hipHostFree(c->pin_ring);
     for (auto& ev : c->pin_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->df_stream) (void)hipStreamDestroy(c->df_stream);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (auto& ev : c->ev_seg) if (ev) (void)hipEventDestroy(ev);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_split_fork) (void)hipEventDestroy(c->ev_split_fork);
@@ -537,7 +570,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     hipStream_t s = c->stream;
     HIP_TRY(c, hipEventRecord(c->ev[0], s));
     HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 8 * sizeof(uint64_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 72 * sizeof(uint64_t), s));
     HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, cnt_of(c), c->ranges, c->stats, s));
     HIP_TRY(c, hipEventRecord(c->ev[1], s));
     HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, c->occ_bits, s));
@@ -548,9 +581,11 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     // against 1.2 + 1.9 apart).  Grids whose x extent the bitmap kernel does not take are forked after the fill.
     if (nx % 4 == 0 && nx <= 16384) if (int r = fork_distance_field(c, s)) return r;
     HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    uint64_t h_stats[8];
+    uint64_t h_stats[72];
     HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    h_stats[7] = 0;
+    for (int k = 8; k < 72; ++k) h_stats[7] += h_stats[k];      // the count pass's striped 64-bit total
     if (h_stats[5]) return fail(c, HVRT_ERR_HIP, "build_grid: the offset scan gave up waiting for a chunk (device fault?)");
     // h_stats[7]: the count pass's own 64-bit total -- the scan's total (h_stats[0]) comes out of 32-bit partial sums
     // and is only meaningful once this one is known to fit; nothing has been scattered yet
@@ -745,9 +780,16 @@ int hvrt_part_rows(int height, int tile_rows, int part, int n_parts) {
     return rows;
 }
 
-int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_frames, int width, int height,
-                                  int spp, uint32_t seed, int tile_rows, int part, int n_parts, int slab_rows,
-                                  void* d_rgb, void* d_hit_id, void* d_t, void* d_counters) {
+// A frame rendered as n launches over consecutive row ranges of one ordered queue (hvrt_render's way of overlapping the
+// PCIe copy with the traversal): tile rows [row[b], row[b + 1]) are complete when ev_seg[b] has happened.  Filled in
+// by render_batch_part when it took that route (used); otherwise the frame is one launch as always.
+struct SegPlan { int n = 0; uint32_t row[9] = {}; bool used = false; };
+
+// hvrt_render_batch_part_device plus d_hits (nullable): one u64 that receives the number of pixels whose sample-0 ray
+// hit a triangle (the host-facing entry points keep it for hvrt_last_hit_count)
+static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_frames, int width, int height,
+                             int spp, uint32_t seed, int tile_rows, int part, int n_parts, int slab_rows,
+                             void* d_rgb, void* d_hit_id, void* d_t, void* d_counters, void* d_hits, SegPlan* plan = nullptr) {
     if (!c) return HVRT_ERR_INVALID;
     if (int r = bind(c)) return r;
     if (int r = require_scene(c)) return r;
@@ -792,11 +834,13 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     RenderArgs ra;
     ra.frames = ds; ra.n_frames = n_frames;
     ra.width = width; ra.height = height; ra.spp = spp; ra.seed = seed;
+    ra.width_f = (float)width; ra.height_f = (float)height; ra.spp_f = (float)spp;
     ra.nearest = c->mode;
     ra.tile_rows = tile_rows; ra.part = part; ra.n_parts = n_parts;
     ra.local_rows = local_rows; ra.slab_rows = slab_rows;
     ra.rgb = (float*)d_rgb; ra.hit_id = (uint32_t*)d_hit_id; ra.t = (float*)d_t;
     ra.counters = (unsigned long long*)d_counters;
+    ra.hits = (unsigned long long*)d_hits;
     ra.tile_counter = c->tile_counter;
     ra.order = reuse ? c->tile_order : nullptr;
     ra.split_tiles = c->split_tiles;
@@ -808,7 +852,8 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     unsigned long long* prev_sum = c->cost_sum + c->cost_parity;
     c->cost_parity ^= 1;
     ra.cost_sum = c->cost_sum + c->cost_parity;
-    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 2 * sizeof(uint32_t), s));   // queue head, abandoned count
+    ra.seg_slots = nullptr; ra.seg = 0;
+    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // queue head, abandoned count, [8..15] the heads of segment launches
     HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     if (reuse && n_tiles) {
@@ -822,8 +867,25 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
             HIP_TRY(c, launch_render_split(scene_of(c), ra, c->n_cus, c->aux_stream));
             HIP_TRY(c, hipEventRecord(c->ev_split_join, c->aux_stream));
         }
-        HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, false, s));
-        if (may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
+        if (plan && plan->n > 1 && plan->n <= 8 && n_frames == 1) {
+            // several launches over consecutive row ranges of this one queue; the long tiles (the queue's head) and the
+            // tiles of k_render_split belong to the first
+            uint32_t* seg_slots = c->tile_counter + 32;      // 9 words of the 64-word scratch
+            HIP_TRY(c, launch_order_segments(c->tile_order, c->order_blocks, (uint32_t)order_blocks, (uint32_t)n_tiles,
+                                             (uint32_t)(width + 7) >> 3, plan->row, plan->n, seg_slots, s));
+            for (int b = 0; b < plan->n; ++b) {
+                RenderArgs rs = ra;
+                rs.seg_slots = seg_slots; rs.seg = b;
+                rs.tile_counter = c->tile_counter + 8 + b;
+                HIP_TRY(c, launch_render(scene_of(c), rs, c->n_cus, false, s));
+                if (b == 0 && may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
+                HIP_TRY(c, hipEventRecord(c->ev_seg[b], s));
+            }
+            plan->used = true;
+        } else {
+            HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, false, s));
+            if (may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
+        }
     } else {
         // no history: the kernel may give up on over-long tiles; k_render_split renders those behind it (none,
         // as a rule: it then finds an empty list and ends)
@@ -841,6 +903,19 @@ int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, 
     memcpy(c->cost_key, key, sizeof key);
     c->cost_valid = true;
     c->render_pending = true;
+    return HVRT_OK;
+}
+
+int hvrt_render_batch_part_device(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_frames, int width, int height,
+                                  int spp, uint32_t seed, int tile_rows, int part, int n_parts, int slab_rows,
+                                  void* d_rgb, void* d_hit_id, void* d_t, void* d_counters) {
+    return render_batch_part(c, frames, n_frames, width, height, spp, seed, tile_rows, part, n_parts, slab_rows,
+                             d_rgb, d_hit_id, d_t, d_counters, nullptr);
+}
+
+int hvrt_last_hit_count(const hvrt_ctx* c, uint64_t* out) {
+    if (!c || !out) return HVRT_ERR_INVALID;
+    *out = c->last_hits;
     return HVRT_OK;
 }
 
@@ -878,11 +953,13 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
     RenderArgs ra = {};
     ra.frames = d_frame; ra.n_frames = 1;
     ra.width = width; ra.height = height; ra.spp = spp; ra.seed = seed;
+    ra.width_f = (float)width; ra.height_f = (float)height; ra.spp_f = (float)spp;
     ra.nearest = c->mode;
     ra.tile_rows = tile_rows; ra.part = part; ra.n_parts = n_parts;
     ra.local_rows = local_rows; ra.slab_rows = local_rows;
     ra.rgb = (float*)d_rgb; ra.hit_id = (uint32_t*)d_hit_id; ra.t = (float*)d_t;
     ra.counters = (unsigned long long*)d_counters;
+    ra.hits = nullptr;
     ra.tile_counter = (uint32_t*)(sp + NOALLOC_QUEUE_HEAD);
     ra.order = nullptr;                 // no history is kept between these calls: rows of tiles from the middle outwards
     ra.split_tiles = nullptr; ra.n_split = nullptr;
@@ -911,15 +988,38 @@ int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int heig
     if (hit_id) if (int r = ensure_bytes(c, c->out_buf[1], c->out_cap[1], npx * 4)) return r;
     if (t) if (int r = ensure_bytes(c, c->out_buf[2], c->out_cap[2], npx * 4)) return r;
     hipStream_t s = c->stream;
-    if (counters) HIP_TRY(c, hipMemsetAsync(c->counters, 0, 16, s));
-    if (int r = hvrt_render_part_device(c, frame, width, height, spp, seed, height, 0, 1,
-                                        rgb ? c->out_buf[0] : nullptr, hit_id ? c->out_buf[1] : nullptr,
-                                        t ? c->out_buf[2] : nullptr, counters ? c->counters : nullptr)) return r;
-    if (rgb) if (int r = download(c, rgb, c->out_buf[0], npx * 12, s)) return r;
-    if (hit_id) if (int r = download(c, hit_id, c->out_buf[1], npx * 4, s)) return r;
-    if (t) if (int r = download(c, t, c->out_buf[2], npx * 4, s)) return r;
-    if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(c->counters, 0, 24, s));      // voxels, tests, hits
+    // A large frame is traced as two launches over one queue (rows of the lower half + every long tile, then the
+    // rest): the first half crosses PCIe while the second is traced.  Needs the tile history (a first launch of a
+    // shape is one launch, copied afterwards).
+    SegPlan plan;
+    const uint32_t tiles_y = (uint32_t)(height + 7) >> 3;
+    // (only when the colours alone are wanted: with three arrays to fetch the copies are the longer part either way)
+    if (npx >= (1u << 21) && tiles_y >= 16 && !hit_id && !t) { plan.n = 2; plan.row[0] = 0; plan.row[1] = tiles_y / 2; plan.row[2] = tiles_y; }
+    if (int r = render_batch_part(c, frame, 1, width, height, spp, seed, height, 0, 1, height,
+                                  rgb ? c->out_buf[0] : nullptr, hit_id ? c->out_buf[1] : nullptr,
+                                  t ? c->out_buf[2] : nullptr, counters ? c->counters : nullptr, c->counters + 2, &plan)) return r;
+    uint64_t h_cnt[3] = { 0, 0, 0 };
+    if (plan.used) {
+        for (int b = 0; b < plan.n; ++b) {
+            const uint64_t y0 = (uint64_t)plan.row[b] * 8, y1 = b + 1 < plan.n ? (uint64_t)plan.row[b + 1] * 8 : (uint64_t)height;
+            const uint64_t p0 = y0 * width, np = (y1 - y0) * width;
+            HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_seg[b], 0));
+            if (rgb) if (int r = download(c, rgb + 3 * p0, (const char*)c->out_buf[0] + 12 * p0, np * 12, c->copy_stream)) return r;
+            if (hit_id) if (int r = download(c, hit_id + p0, (const char*)c->out_buf[1] + 4 * p0, np * 4, c->copy_stream)) return r;
+            if (t) if (int r = download(c, t + p0, (const char*)c->out_buf[2] + 4 * p0, np * 4, c->copy_stream)) return r;
+        }
+        HIP_TRY(c, hipMemcpyAsync(h_cnt, c->counters, sizeof h_cnt, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(h_cnt, c->counters, sizeof h_cnt, hipMemcpyDeviceToHost, s));
+        if (rgb) if (int r = download(c, rgb, c->out_buf[0], npx * 12, s)) return r;
+        if (hit_id) if (int r = download(c, hit_id, c->out_buf[1], npx * 4, s)) return r;
+        if (t) if (int r = download(c, t, c->out_buf[2], npx * 4, s)) return r;
+    }
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (counters) { counters[0] = h_cnt[0]; counters[1] = h_cnt[1]; }
+    c->last_hits = h_cnt[2];
     c->tm.render_ms = ms_between(c->ev[6], c->ev[7]);
     c->render_pending = false;
     return HVRT_OK;
@@ -948,16 +1048,19 @@ int hvrt_render_views_rgb8(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_f
     if (int r = ensure_bytes(c, c->out_buf[0], c->out_cap[0], f_bytes + npx * 3 + 16)) return r;
     if (hit_id) if (int r = ensure_bytes(c, c->out_buf[1], c->out_cap[1], npx * 4)) return r;
     hipStream_t s = c->stream;
-    if (counters) HIP_TRY(c, hipMemsetAsync(c->counters, 0, 16, s));
-    if (int r = hvrt_render_batch_part_device(c, frames, n_frames, width, height, 1, 0, height, 0, 1, height,
-                                              c->out_buf[0], hit_id ? c->out_buf[1] : nullptr, nullptr,
-                                              counters ? c->counters : nullptr)) return r;
+    HIP_TRY(c, hipMemsetAsync(c->counters, 0, 24, s));      // voxels, tests, hits
+    if (int r = render_batch_part(c, frames, n_frames, width, height, 1, 0, height, 0, 1, height,
+                                  c->out_buf[0], hit_id ? c->out_buf[1] : nullptr, nullptr,
+                                  counters ? c->counters : nullptr, c->counters + 2)) return r;
     uint8_t* d8 = (uint8_t*)c->out_buf[0] + f_bytes;
     HIP_TRY(c, launch_quantise_rgb8((const float*)c->out_buf[0], npx * 3, d8, s));
+    uint64_t h_cnt[3] = { 0, 0, 0 };
+    HIP_TRY(c, hipMemcpyAsync(h_cnt, c->counters, sizeof h_cnt, hipMemcpyDeviceToHost, s));
     if (int r = download(c, rgb8, d8, npx * 3, s)) return r;
     if (hit_id) if (int r = download(c, hit_id, c->out_buf[1], npx * 4, s)) return r;
-    if (counters) HIP_TRY(c, hipMemcpyAsync(counters, c->counters, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    if (counters) { counters[0] = h_cnt[0]; counters[1] = h_cnt[1]; }
+    c->last_hits = h_cnt[2];
     c->tm.render_ms = ms_between(c->ev[6], c->ev[7]);
     c->render_pending = false;
     return HVRT_OK;
@@ -968,8 +1071,12 @@ int hvrt_assemble_parts_device(hvrt_ctx* c, const void* d_parts, int width, int 
     if (!c) return HVRT_ERR_INVALID;
     if (int r = bind(c)) return r;
     if (!d_parts || !d_frame) return fail(c, HVRT_ERR_INVALID, "assemble: null pointer");
-    if (width < 1 || height < 1 || tile_rows < 1 || n_parts < 1 || bytes_per_pixel < 4 || (bytes_per_pixel & 3))
-        return fail(c, HVRT_ERR_INVALID, "assemble: bad geometry");
+    // rows are moved as 4-byte words: 12 (float rgb) and 4 (hit id, t) bytes per pixel always qualify, 3 (8-bit rgb)
+    // when the row does (width a multiple of 4)
+    if (width < 1 || height < 1 || tile_rows < 1 || n_parts < 1 || bytes_per_pixel < 1 ||
+        (((int64_t)width * bytes_per_pixel) & 3) || ((uintptr_t)d_parts & 3) || ((uintptr_t)d_frame & 3))
+        return fail(c, HVRT_ERR_INVALID, "assemble: bad geometry (a row of %d pixels x %d bytes must be a whole number of "
+                    "4-byte words, buffers 4-byte aligned)", width, bytes_per_pixel);
     for (int p = 0; p < n_parts; ++p)
         if (hvrt_part_rows(height, tile_rows, p, n_parts) > slab_rows)
             return fail(c, HVRT_ERR_INVALID, "assemble: slab_rows %d too small for part %d", slab_rows, p);

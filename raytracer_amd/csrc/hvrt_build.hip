@@ -5,7 +5,7 @@
 //   k_count       one lane per triangle: AABB -> inclusive voxel range (SceneCreator.cpp:23-37,
 //                 177-188, GeometryUtils.cpp:43-51), atomic count per voxel with run-aggregated
 //                 atomics; big ranges are spread over the whole wave; the exact 64-bit number of
-//                 references goes to stats[7] (overflow check before anything is scattered)
+//                 references goes to stats[8..71] (overflow check before anything is scattered)
 //   k_scan        exclusive scan of the counts in flat order ix + nx*(iy + ny*iz) in ONE pass over
 //                 the array (chained scan with decoupled look-back, 32768 counters per workgroup);
 //                 also leaves the one-bit-per-voxel occupancy map for the distance field
@@ -174,10 +174,12 @@ __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, u
         ranges[3ull * t + 2] = (uint32_t)lz | ((uint32_t)hz << 16);
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
-    // the number of references, exactly, in 64 bits (stats[7]): the scan adds the per-voxel counters up in 32-bit
-    // partial sums, which more than 2^32 - 1 references would wrap before the host could see them
+    // the number of references, exactly, in 64 bits: the scan adds the per-voxel counters up in 32-bit partial sums,
+    // which more than 2^32 - 1 references would wrap before the host could see them.  Summed per wave into 64 striped
+    // words (stats[8 + blockIdx % 64]; the host adds them up): thousands of atomics on ONE word cost the count pass
+    // more than its own work on a million triangles
     const uint64_t vol = wave_sum64(nonempty ? (uint64_t)(hx - lx + 1) * (uint64_t)(hy - ly + 1) * (uint64_t)(hz - lz + 1) : 0ull);
-    if ((threadIdx.x & 63u) == 0u && vol) atomicAdd((unsigned long long*)&stats[7], (unsigned long long)vol);
+    if ((threadIdx.x & 63u) == 0u && vol) atomicAdd((unsigned long long*)&stats[8 + (blockIdx.x & 63u)], (unsigned long long)vol);
     walk_range<false>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
 }
 

@@ -51,6 +51,7 @@ struct RenderArgs {
     int n_frames;
     int width, height;       // full frame
     int spp;
+    float width_f, height_f, spp_f;   // the same as floats (exact), so that the kernel holds them in scalar registers
     uint32_t seed;
     int nearest;             // 0: the reference's traversal; 1: nearest-hit mode (hvrt_set_mode)
     int tile_rows, part, n_parts;
@@ -60,6 +61,7 @@ struct RenderArgs {
     uint32_t* hit_id;        // nullable
     float* t;                // nullable
     unsigned long long* counters;  // 2 x u64, nullable
+    unsigned long long* hits;      // 1 x u64, nullable: += pixels whose sample-0 ray hit a triangle (the reference's "Ray hits" log line)
     uint32_t* tile_counter;  // persistent-thread work queue head (zeroed before launch)
     // Work-queue order.  Slot q of the queue is tile order[q] (null: q itself); a tile is 8x8 pixels of one
     // frame, numbered frame-major.  Every launch leaves the duration of each tile (shader clocks / 16) in
@@ -78,13 +80,18 @@ struct RenderArgs {
     long long abort_ticks;   // in ticks of the constant 100 MHz clock (wall_clock64), per sample of a pixel
     uint32_t* tile_cost;
     unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
+    // A frame rendered as several launches over consecutive ranges of ONE ordered queue (the host-facing hvrt_render:
+    // the rows a launch completes travel over PCIe while the next launch traces): this launch takes the slots
+    // [seg_slots[seg], seg_slots[seg + 1]) and its queue head starts at 0.  Null: the whole queue.
+    const uint32_t* seg_slots;
+    int seg;
 };
 
 // ---- launchers (hvrt_build.hip) ----
 constexpr int SCAN_CHUNK = 32768;  // counters per scan workgroup (1024 threads x 32)
 
 hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t n_tris, hipStream_t s);
-// stats[7] += the exact number of references (64-bit; zero on entry)
+// stats[8 .. 71] += the exact number of references, striped over 64 words (64-bit; zero on entry)
 hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
                         uint32_t* ranges, uint64_t* stats, hipStream_t s);
 // in-place exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64 of scratch.
@@ -125,6 +132,11 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
                               uint32_t* wants_split, hipStream_t s);
+// seg_slots[0..n_seg] <- the slot ranges of n_seg launches over the queue launch_order_build left: launch b covers the
+// tiles of tile rows [row_bounds[b], row_bounds[b + 1]) that are in k_render's queue behind the long ones; launch 0
+// also takes the long tiles, which sit at the queue's head (row_bounds[0] = 0, row_bounds[n_seg] = tile rows; n_seg <= 8)
+hipError_t launch_order_segments(const uint32_t* order, const uint32_t* block_count, uint32_t n_blocks, uint32_t n_tiles,
+                                 uint32_t tiles_x, const uint32_t* row_bounds, int n_seg, uint32_t* seg_slots, hipStream_t s);
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n,
                         hvrt_hit* out, unsigned long long* counters, int nearest, hipStream_t s);
 hipError_t launch_quantise_rgb8(const float* rgb /* 16-B aligned */, uint64_t n_values, uint8_t* out /* 4-B aligned */, hipStream_t s);

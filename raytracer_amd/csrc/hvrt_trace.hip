@@ -84,6 +84,14 @@ __device__ __forceinline__ void ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, On
 // the mask of lanes for which b holds, straight from the compare (HIP's __ballot goes through an integer)
 __device__ __forceinline__ unsigned long long any_lane(bool b) { return __builtin_amdgcn_ballot_w64(b); }
 
+// The lane number, worked out where it is needed (two instructions) rather than kept in a register for the whole
+// kernel: k_render has none to spare.  The opaque zero keeps the compiler from hoisting it back out of the loops.
+__device__ __forceinline__ int lane_now() {
+    unsigned z = 0;
+    asm volatile("" : "+v"(z));
+    return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
+
 // Selects on a lane mask held in a scalar register pair, in the VOP3 encoding.  Why by hand: for `c ? a : b` with c
 // the AND of two compares the compiler forms the mask with s_and_b64 into vcc and selects with the VOP2
 // v_cndmask_b32, and on gfx950 a VOP2 v_cndmask_b32 whose vcc was last written by the SCALAR unit blocks its SIMD for
@@ -447,10 +455,10 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 }
 __device__ __forceinline__ float lane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
-template <bool COUNT, bool NEAREST, bool ABORT>
+// SAME_ORIGIN: every lane's ray starts at the same point (k_render: the camera), so the start voxel is a scalar
+template <bool COUNT, bool NEAREST, bool ABORT, bool SAME_ORIGIN = false>
 __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, V3 d, bool alive, float4* __restrict__ win, long long deadline = 0) {
     const GridParams& g = sc.g;
-    const int lane = (int)(threadIdx.x & 63u);
     TraceResult r;
     r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
 #if defined(HVRT_ABLATE) && HVRT_ABLATE >= 3      // 3 = no walk: what a tile costs before and after its rays (4: and no pixel stores, 5: and no duration store, 6: and no ray set-up)
@@ -458,6 +466,9 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
 #endif
 
     V3 st = o;
+    // (a scalar start point is taken through an opaque copy, so that the start voxel is worked out here, per ray and
+    // into scalar registers, and not hoisted out of the caller's loops into vector registers that must be spilled)
+    if (SAME_ORIGIN && !NEAREST) asm volatile("" : "+v"(st.x), "+v"(st.y), "+v"(st.z));
     if (NEAREST) {
         const float ivx = 1.0f / d.x, ivy = 1.0f / d.y, ivz = 1.0f / d.z;
         const float tx1 = (g.mnx - o.x) * ivx, tx2 = (g.bxx - o.x) * ivx;
@@ -469,9 +480,12 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         const float t0 = max2(tn, 0.0f);
         st = { o.x + d.x * t0, o.y + d.y * t0, o.z + d.z * t0 };
     }
-    const int ix = clampi(f2i((st.x - g.mnx) / g.vsx), 0, g.nx - 1);
-    const int iy = clampi(f2i((st.y - g.mny) / g.vsy), 0, g.ny - 1);
-    const int iz = clampi(f2i((st.z - g.mnz) / g.vsz), 0, g.nz - 1);
+    int ix = clampi(f2i((st.x - g.mnx) / g.vsx), 0, g.nx - 1);
+    int iy = clampi(f2i((st.y - g.mny) / g.vsy), 0, g.ny - 1);
+    int iz = clampi(f2i((st.z - g.mnz) / g.vsz), 0, g.nz - 1);
+    if (SAME_ORIGIN && !NEAREST) {      // (the nearest-hit mode starts where each ray enters the grid)
+        ix = __builtin_amdgcn_readfirstlane(ix); iy = __builtin_amdgcn_readfirstlane(iy); iz = __builtin_amdgcn_readfirstlane(iz);
+    }
     const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;
     float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
     // (the absolute values are taken here, once: left to the compiler they become |x| source modifiers on every
@@ -491,7 +505,6 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
     uint32_t f = (uint32_t)ix + (uint32_t)g.nx * (uint32_t)iy + plane * (uint32_t)iz;
     const uint32_t* __restrict__ offs = sc.offsets;
     const uint32_t fw = (uint32_t)sc.face_words;
-    const uint32_t facex = (px ? 0u : 1u) * fw, facey = (py ? 2u : 3u) * fw, facez = (pz ? 4u : 5u) * fw;
     uint32_t last = 0;
 #ifndef HVRT_DIAG
     if (COUNT) r.nv = alive ? 1u : 0u;
@@ -569,7 +582,13 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         if (alive) { const uint32_t* pv = offs + f; b0 = pv[0]; b1 = pv[1]; }
 #endif
         const bool entered = last != 0u;
-        const uint32_t face = sel(any_lane(last == fsx) & (g.nx > 1 ? ~0ull : 0ull), facex, sel(any_lane(last == fsy) & (g.ny > 1 ? ~0ull : 0ull), facey, facez));
+        // the face through which the voxel was entered (word offset of its bit array: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z,
+        // 5 +z neighbour), from the last step's increment -- the walking direction is in the increments' signs, so
+        // nothing but `last` is kept for it.  A surviving x step implies nx > 1, so the axes are told apart in this
+        // order with their extent (in a 1-wide grid fsx == fsy or fsy == fsz)
+        const uint32_t face = sel(any_lane(last == fsx) & (g.nx > 1 ? ~0ull : 0ull), sel(any_lane(fsx == 1u), 0u, fw),
+                                  sel(any_lane(last == fsy) & (g.ny > 1 ? ~0ull : 0ull), sel(any_lane(fsy == (uint32_t)g.nx), 2u * fw, 3u * fw),
+                                      sel(any_lane(fsz == plane), 4u * fw, 5u * fw)));
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         const uint32_t n = b1 - b0;       // 0 for lanes without a ray
         uint32_t c = 0;
@@ -598,6 +617,7 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 // fetch for the wave, parked in the wave's LDS window; every lane then tests the entries that ANY lane
                 // has to test (an entry one lane skips was tested by that ray one voxel ago and missed, so testing it
                 // again changes nothing), reading each record from LDS at a wave-uniform address (a broadcast)
+                const int lane = lane_now();
                 const float4 A = sc.ref_rec[3ull * ubase + (uint32_t)lane];
                 uint32_t um = wave_or(todo);
 #ifdef HVRT_DIAG   // diagnostic build only: what the two counters mean depends on HVRT_DIAG (scripts/diag_counts.py)
@@ -626,7 +646,7 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 }
             } else {
 #ifdef HVRT_DIAG
-                if (COUNT && HVRT_DIAG == 11 && lane == 0) r.nt += 64;                  // per-lane (fallback) chunks
+                if (COUNT && HVRT_DIAG == 11 && lane_now() == 0) r.nt += 64;                  // per-lane (fallback) chunks
 #endif
                 while (todo) {
                     const uint32_t k = (uint32_t)__builtin_ctz(todo);
@@ -699,6 +719,26 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 // What both render kernels do for one pixel: the spp samples of pixel (x, y) of frame `cf` -- renderPixel
 // (OctreeLikeRayTracer.cpp:73-74; pixel corner, jitter is 0 at spp 1), generateRay (:361-364), the traversal and
 // the shading.  Returns false when ABORT is set and a walk gave up (nothing of the pixel is valid then).
+// Pixel of lane `lane` in tile (tx, ty) of a part: column x, row lr inside the part's slab, row y of the frame (tile k
+// of the image's row tiles belongs to part k % n_parts).  Worked out wherever it is needed -- before the walk, per
+// sample for the jitter, after the walk for the stores -- from the two scalars tx, ty instead of being carried through
+// the walk in vector registers: k_render has no register to spare at seven waves per SIMD (the asm statements keep
+// the compiler from hoisting the lane-only parts out of the tile loop, where they would have to be spilled).
+__device__ __forceinline__ void pixel_coords(const RenderArgs& ra, uint32_t tx, uint32_t ty, int lane, int& x, int& lr, int& y) {
+    if (lane < 0) lane = lane_now();      // k_render: not even the lane number is carried (it would be spilled)
+    else asm volatile("" : "+v"(lane));
+    x = (int)(tx * 8u) + (lane & 7);
+    lr = (int)(ty * 8u) + (lane >> 3);
+    if (ra.n_parts == 1) {
+        y = lr;
+    } else {
+        int tr = ra.tile_rows;
+        asm volatile("" : "+s"(tr));
+        const int kl = lr / tr;
+        y = (kl * ra.n_parts + ra.part) * tr + (lr - kl * tr);
+    }
+}
+
 struct PixelResult {
     V3 rgb;              // mean of the samples
     uint32_t hit; float t;   // sample 0's
@@ -706,7 +746,8 @@ struct PixelResult {
 };
 template <bool COUNT, bool INLINE, bool NEAREST, int RAYS, bool ABORT>
 __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArgs& ra, const hvrt_camera_frame* __restrict__ cf,
-                                             int x, int y, bool alive, float4* __restrict__ win, long long wall0, PixelResult& out) {
+                                             uint32_t tx, uint32_t ty, int lane, int px_x, int px_y, bool alive,
+                                             float4* __restrict__ win, long long wall0, PixelResult& out) {
     const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };          // wave-uniform: scalar loads
     const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
     const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
@@ -714,15 +755,19 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
     V3 acc = { 0.0f, 0.0f, 0.0f };
     out.hit = HVRT_MISS; out.t = FLT_MAX; out.nv = 0; out.nt = 0;
     for (int s = 0; s < ra.spp; ++s) {
+        // RAYS == 64 (k_render): the pixel's coordinates are worked out again per sample (see pixel_coords);
+        // k_render_split's lanes share pixels and pass theirs in
+        int x = px_x, y = px_y, lr_unused = 0;
+        if (RAYS == 64) pixel_coords(ra, tx, ty, lane, x, lr_unused, y);
         float jx = 0.0f, jy = 0.0f;
         if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
-        const float u = ((float)x + jx) / (float)ra.width;
-        const float v = ((float)y + jy) / (float)ra.height;
+        const float u = ((float)x + jx) / ra.width_f;
+        const float v = ((float)y + jy) / ra.height_f;
         const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
         TraceResult r;
         // the wave-synchronous walk wants every lane of the wave in the call, with or without a ray (alive);
         // the per-lane walks are only ever called by lanes that have one
-        if constexpr (INLINE && RAYS == 64) r = trace_ray_wave<COUNT, NEAREST, ABORT>(sc, org, d, alive, win, wall0 + ra.abort_ticks * (s + 1));
+        if constexpr (INLINE && RAYS == 64) r = trace_ray_wave<COUNT, NEAREST, ABORT, true>(sc, org, d, alive, win, wall0 + ra.abort_ticks * (s + 1));
         else r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, wall0 + ra.abort_ticks * (s + 1));
         if (ABORT && r.tri == HVRT_ABORTED) return false;
         const V3 c = shade(sc, r, org, v);
@@ -730,7 +775,7 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
         if (s == 0) { out.hit = r.tri; out.t = r.t; }
         if (COUNT) { out.nv += r.nv; out.nt += r.nt; }
     }
-    if (ra.spp > 1) { const float n = (float)ra.spp; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+    if (ra.spp > 1) { const float n = ra.spp_f; acc = { acc.x / n, acc.y / n, acc.z / n }; }
     out.rgb = acc;
     return true;
 }
@@ -751,14 +796,18 @@ template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render(SceneDev sc, RenderArgs ra) {
     __shared__ float4 lds_win[4][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
-    const int lane = threadIdx.x & 63;
+    // (the lane number is worked out where it is needed, lane_now(): a register held for it would be spilled)
+    float4* const win = lds_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t tiles_frame = tiles_x * tiles_y;
     const uint32_t n_tiles = tiles_frame * (uint32_t)ra.n_frames;
-    // with an order, the tiles that k_render_split takes are not in this kernel's queue
-    const uint32_t n_queue = ra.order ? n_tiles - *ra.n_split : n_tiles;
+    // with an order, the tiles that k_render_split takes are not in this kernel's queue; a launch may be given a
+    // range of the queue's slots only (RenderArgs::seg_slots)
+    const uint32_t slot0 = ra.seg_slots ? ra.seg_slots[ra.seg] : 0u;
+    const uint32_t n_queue = ra.seg_slots ? ra.seg_slots[ra.seg + 1] : (ra.order ? n_tiles - *ra.n_split : n_tiles);
     uint64_t tot_nv = 0, tot_nt = 0;
+    uint32_t tot_hits = 0;                // wave-uniform
     unsigned long long wave_cost = 0;     // wave-uniform
     uint32_t given_up = 0xFFFFFFFFu;      // wave-uniform: the tile the previous iteration gave up on (see below)
     // The queue head is ONE word, and one word takes about 88 returning atomics per microsecond from the whole chip
@@ -776,24 +825,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
     const uint32_t n_waves = gridDim.x * 4u;
 
     for (;;) {
-        if (ABORT && lane == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
+        if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
         given_up = 0xFFFFFFFFu;
         if (slot == slot_end) {
             uint32_t got = 0;
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31       // clocks spent waiting for the queue head | clocks in the loop, per wave
             const long long pull0 = clock64();
 #endif
-            if (lane == 0) got = atomicAdd(ra.tile_counter, batch);
-            slot = (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
+            if (lane_now() == 0) got = atomicAdd(ra.tile_counter, batch);
+            slot = slot0 + (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31
-            if (COUNT && lane == 0) { tot_nv += (uint64_t)(clock64() - pull0); tot_nt += 1; }
+            if (COUNT && lane_now() == 0) { tot_nv += (uint64_t)(clock64() - pull0); tot_nt += 1; }
 #endif
             if (slot >= n_queue) break;
             slot_end = slot + batch < n_queue ? slot + batch : n_queue;
             batch_clk0 = clock64();
         }
         uint32_t pulled = 0;
-        if (lane == 0) {
+        if (lane_now() == 0) {
             if (ra.order) {
                 pulled = ra.order[slot];
             } else {
@@ -817,11 +866,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
         const long long wall0 = ABORT ? (long long)wall_clock64() : 0;
         const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
         const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
-        const int x = (int)(tx * 8u) + (lane & 7);
-        const int lr = (int)(ty * 8u) + (lane >> 3);
-        // local row -> global row: tile k of the image belongs to part k % n_parts
-        const int kl = lr / ra.tile_rows;
-        const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
+        int x, lr, y;
+        pixel_coords(ra, tx, ty, -1, x, lr, y);
         // A tile whose rays are still inside long lists a millisecond after they set out is not finished here:
         // the wave drops it (nothing of it is written or counted) and k_render_split, launched behind this
         // kernel, renders it with 16 waves.  This is what bounds a launch that has no history of the scene yet;
@@ -835,13 +881,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
 #if defined(HVRT_ABLATE) && HVRT_ABLATE >= 6
             px.rgb = { 0.5f, 0.5f, (float)x }; px.hit = HVRT_MISS; px.t = FLT_MAX;
 #else
-            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, inside, lds_win[threadIdx.x >> 6], wall0, px);
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, tx, ty, -1, 0, 0, inside, win, wall0, px);
 #endif
 #if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)
-            if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr, x, px);
+            int x2, lr2, y2;
+            pixel_coords(ra, tx, ty, -1, x2, lr2, y2);
+            if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr2, x2, px);
 #endif
         } else if (inside) {
-            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, x, y, true, nullptr, wall0, px);
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, tx, ty, -1, 0, 0, true, nullptr, wall0, px);
             // the wave decides; a lane that finished its pixel holds its stores back until then
             if (!ABORT || any_lane(gave_up) == 0ull) store_pixel(ra, fi, lr, x, px);
         }
@@ -859,6 +907,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
 #if !defined(HVRT_DIAG) || HVRT_DIAG != 31
             else if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
 #endif
+            if (ra.hits && !dropped) tot_hits += (uint32_t)__builtin_popcountll(any_lane(inside && px.hit != HVRT_MISS));
         }
         if (slot == slot_end) {
             // size of the next pull: PULL_CLOCKS of work at this batch's cost per tile, halved while it exceeds the
@@ -869,8 +918,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
             while (batch > 1u && batch * n_waves > left) batch >>= 1;
         }
     }
-    if (ABORT && lane == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
+    if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
+    const int lane = lane_now();
     if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
+    if (lane == 0 && tot_hits) atomicAdd(ra.hits, (unsigned long long)tot_hits);
     if (COUNT && ra.counters) {
         tot_nv = wave_sum64(tot_nv);
         tot_nt = wave_sum64(tot_nt);
@@ -911,10 +962,14 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
         const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
             PixelResult px;
-            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, x, y, true, nullptr, wall0, px);
+            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, 0u, 0u, lane, x, y, true, nullptr, wall0, px);
             if (slice == 0) {
                 store_pixel(ra, fi, lr, x, px);
                 if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
+            }
+            if (ra.hits) {
+                const uint32_t nh = (uint32_t)__builtin_popcountll(any_lane(slice == 0 && px.hit != HVRT_MISS));
+                if (nh && lane == (int)__builtin_ctzll(any_lane(true))) atomicAdd(ra.hits, (unsigned long long)nh);   // the first lane that is here
             }
         }
         const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
@@ -1016,6 +1071,27 @@ __global__ __launch_bounds__(256) void k_order_place(uint32_t* __restrict__ cost
     if (cls == 2) { split_tiles[before2] = i; cost[i] = COST_SPLIT_FLAG; }
     else if (cls == 1) order[before1] = i;
     else order[n_long + (i - before2 - before1)] = i;
+}
+
+// Slot ranges for a frame rendered as several launches over one queue (RenderArgs::seg_slots): behind the long tiles
+// the queue is in natural (tile index) order, so the first slot of tile row r is found by bisection.
+struct SegBounds { uint32_t row[9]; };
+__global__ __launch_bounds__(64) void k_order_segments(const uint32_t* __restrict__ order, const uint32_t* __restrict__ block_count,
+                                                        uint32_t n_blocks, uint32_t n_tiles, uint32_t tiles_x, SegBounds b, int n_seg,
+                                                        uint32_t* __restrict__ seg_slots) {
+    const int i = (int)threadIdx.x;
+    if (i > n_seg) return;
+    const uint32_t n_split = block_count[n_blocks], n_long = block_count[2 * n_blocks + 1];
+    const uint32_t n_queue = n_tiles - n_split;
+    if (i == 0) { seg_slots[0] = 0; return; }
+    if (i == n_seg) { seg_slots[i] = n_queue; return; }
+    const uint32_t first_tile = b.row[i] * tiles_x;
+    uint32_t lo = n_long, hi = n_queue;                  // first slot in [n_long, n_queue) whose tile is >= first_tile
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (order[mid] < first_tile) lo = mid + 1; else hi = mid;
+    }
+    seg_slots[i] = lo;
 }
 
 // traceRay batch: one lane per ray, RayHit records out (OctreeLikeRayTracer.cpp:124-126, :283-288).
@@ -1153,6 +1229,15 @@ hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsig
     return hipGetLastError();
 }
 
+hipError_t launch_order_segments(const uint32_t* order, const uint32_t* block_count, uint32_t n_blocks, uint32_t n_tiles,
+                                 uint32_t tiles_x, const uint32_t* row_bounds, int n_seg, uint32_t* seg_slots, hipStream_t s) {
+    if (n_seg < 1 || n_seg > 8) return hipErrorInvalidValue;
+    SegBounds b;
+    for (int i = 0; i <= n_seg; ++i) b.row[i] = row_bounds[i];
+    k_order_segments<<<1, 64, 0, s>>>(order, block_count, n_blocks, n_tiles, tiles_x, b, n_seg, seg_slots);
+    return hipGetLastError();
+}
+
 hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* dirs, uint32_t n, hvrt_hit* out,
                         unsigned long long* counters, int nearest, hipStream_t s) {
     if (n == 0) return hipSuccess;
@@ -1175,7 +1260,7 @@ hipError_t launch_quantise_rgb8(const float* rgb, uint64_t n_values, uint8_t* ou
 
 hipError_t launch_assemble(const void* parts, int width, int height, int tile_rows, int n_parts, int slab_rows,
                            int bytes_per_pixel, void* frame, hipStream_t s) {
-    const int words = width * (bytes_per_pixel / 4);
+    const int words = (int)(((int64_t)width * bytes_per_pixel) / 4);
     if (words == 0 || height == 0) return hipSuccess;
     int bx = (words + 255) / 256;
     if (bx > 64) bx = 64;

@@ -8,6 +8,9 @@ The path shards by image row tiles with no exchange during compute (SURVEY.md se
   * ONE collective per frame gathers the slabs (all_gather of equal, padded slabs over xGMI) and a
     de-interleave kernel (hvrt_assemble_parts_device) rebuilds the frame.  There is no reduction, so an
     N-GPU frame is bytewise the 1-GPU frame.
+  * what crosses xGMI is, by default, the 8-bit image (rgb8=True): every rank converts its slab on the device with
+    the reference's own rule (ImageSaver.h:28-33, hvrt_quantise_rgb8_device) before the collective, so 3 bytes per
+    pixel move instead of 12; the float frame is exchanged when the caller asks (rgb8=False).
 
 torch is plumbing here (device buffers, streams, the process group); every kernel is libhvrt's.
 The collective helpers are device-agnostic so that the choreography is testable on CPU with gloo.
@@ -123,47 +126,67 @@ class DistributedRenderer:
         return mn, mx, vs3
 
     # ---- frames --------------------------------------------------------------------------------
-    def alloc(self, width: int, height: int, n_frames: int = 1):
+    def alloc(self, width: int, height: int, n_frames: int = 1, rgb8: bool = False):
+        """rgb8: quantise every slab on the device and exchange 3 bytes per pixel (width must be a multiple of 4)."""
         part = Partition(height, self.tile_rows, self.world)
         self.part = part
+        if rgb8 and width % 4:
+            raise ValueError("rgb8 exchange: the image width must be a multiple of 4 (rows move as 4-byte words)")
+        self.rgb8 = rgb8
         self.local = torch.zeros((n_frames, part.slab_rows, width, 3), dtype=torch.float32, device=self.device)
-        self.gathered = [torch.empty((self.world, part.slab_rows, width, 3), dtype=torch.float32, device=self.device)
+        dt = torch.uint8 if rgb8 else torch.float32
+        if rgb8:
+            self.local8 = torch.zeros((n_frames, part.slab_rows, width, 3), dtype=torch.uint8, device=self.device)
+        self.gathered = [torch.empty((self.world, part.slab_rows, width, 3), dtype=dt, device=self.device)
                          for _ in range(n_frames)]
-        self.frames = torch.empty((n_frames, height, width, 3), dtype=torch.float32, device=self.device)
+        self.frames = torch.empty((n_frames, height, width, 3), dtype=dt, device=self.device)
         self.width, self.height = width, height
+
+    def _quantise(self, src: torch.Tensor, dst: torch.Tensor):
+        self.ctx.quantise_rgb8_device(src.data_ptr(), src.numel(), dst.data_ptr())
 
     def render_frames(self, cam_frames, spp: int = 1, seed: int = 0):
         """Renders this rank's tiles of every frame, gathers each frame as soon as it is rendered (the
-        next frame's traversal overlaps the previous frame's all_gather), reassembles on every rank."""
+        next frame's traversal overlaps the previous frame's all_gather), reassembles on every rank.
+        Returns float frames, or uint8 frames when allocated with rgb8=True."""
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
+        rgb8 = getattr(self, "rgb8", False)
+        send = self.local8 if rgb8 else self.local
         for f, cam in enumerate(cam_frames):
             self.ctx.render_part_device(cam, self.width, self.height, spp, seed, self.tile_rows, self.rank,
                                         self.world, d_rgb=self.local[f].data_ptr())
+            if rgb8:
+                self._quantise(self.local[f], self.local8[f])
             if self.world == 1:
                 continue
             ev = self.stream.record_event()
             cur.wait_event(ev)
-            dist.all_gather_into_tensor(self.gathered[f], self.local[f])
+            dist.all_gather_into_tensor(self.gathered[f], send[f])
         if self.world == 1:
             cur.wait_stream(self.stream)
-            return self.local[:, :self.height]          # one part: the slab is the frame
+            return send[:, :self.height]                # one part: the slab is the frame
         self.stream.wait_stream(cur)
         for f in range(len(cam_frames)):
             self.ctx.assemble_parts_device(self.gathered[f].data_ptr(), self.width, self.height, self.tile_rows,
-                                           self.world, self.part.slab_rows, 12, self.frames[f].data_ptr())
+                                           self.world, self.part.slab_rows, 3 if rgb8 else 12, self.frames[f].data_ptr())
         cur.wait_stream(self.stream)
         return self.frames
 
     # ---- batches of `world` frames, one owner per frame (weak scaling) ---------------------------
-    def alloc_batch(self, width: int, height: int):
-        """Double-buffered: batch k renders while batch k-1 is exchanged."""
+    def alloc_batch(self, width: int, height: int, rgb8: bool = False):
+        """Double-buffered: batch k renders while batch k-1 is exchanged.  rgb8: exchange the 8-bit image."""
         part = Partition(height, self.tile_rows, self.world)
         self.part = part
+        if rgb8 and width % 4:
+            raise ValueError("rgb8 exchange: the image width must be a multiple of 4 (rows move as 4-byte words)")
+        self.rgb8 = rgb8
         shape = (self.world, part.slab_rows, width, 3)
+        dt = torch.uint8 if rgb8 else torch.float32
         self.b_local = [torch.zeros(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.b_recv = [torch.empty(shape, dtype=torch.float32, device=self.device) for _ in range(2)]
-        self.b_frame = [torch.empty((height, width, 3), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.b_send = [torch.zeros(shape, dtype=torch.uint8, device=self.device) for _ in range(2)] if rgb8 else self.b_local
+        self.b_recv = [torch.empty(shape, dtype=dt, device=self.device) for _ in range(2)]
+        self.b_frame = [torch.empty((height, width, 3), dtype=dt, device=self.device) for _ in range(2)]
         self.width, self.height = width, height
         self._batch = 0
         self._pending = None       # (buffer index, work) of the batch whose exchange is in flight
@@ -175,12 +198,13 @@ class DistributedRenderer:
         b, work = self._pending
         self._pending = None
         if self.world == 1:
-            return self.b_local[b][0, :self.height]
+            return self.b_send[b][0, :self.height]
         with torch.cuda.stream(self.stream):
             if work is not None:
                 work.wait()                                # stream-level wait, the host does not block
             self.ctx.assemble_parts_device(self.b_recv[b].data_ptr(), self.width, self.height, self.tile_rows,
-                                           self.world, self.part.slab_rows, 12, self.b_frame[b].data_ptr())
+                                           self.world, self.part.slab_rows, 3 if self.rgb8 else 12,
+                                           self.b_frame[b].data_ptr())
         return self.b_frame[b]
 
     def render_batch(self, cam_frames, spp: int = 1, seed: int = 0):
@@ -198,10 +222,12 @@ class DistributedRenderer:
         self.ctx.render_batch_part_device(list(cam_frames), self.width, self.height, spp, seed, self.tile_rows,
                                           self.rank, self.world, self.part.slab_rows,
                                           d_rgb=self.b_local[b].data_ptr())
+        if self.rgb8:
+            self._quantise(self.b_local[b], self.b_send[b])
         work = None
         if self.world > 1:
             cur.wait_event(self.stream.record_event())     # RCCL's stream orders itself after `cur`
-            _, work = exchange_parts(self.b_local[b], self.b_recv[b], async_op=True)
+            _, work = exchange_parts(self.b_send[b], self.b_recv[b], async_op=True)
         done = self._finish_pending()                      # batch k-1: exchanged while batch k rendered
         self._pending = (b, work)
         cur.wait_stream(self.stream)

@@ -133,15 +133,17 @@ std::vector<Vec3> HipVoxelRayTracer::render(const Camera& cam, int width, int he
     hvrt_camera_frame fr;
     hvrt_make_camera_frame(&cam.position.x, &cam.lookAt.x, &cam.up.x, cam.fov, cam.aspectRatio, &fr);
     std::vector<Vec3> frame((size_t)width * height);
-    hit_ids_.assign((size_t)width * height, HVRT_MISS);
+    // the hit-id image is fetched only when the caller asked for it (keepHitIds): it is a third more bytes over
+    // PCIe, and the reference's render() returns colours only; the hit COUNT it logs comes from the device
+    if (keep_hit_ids_) hit_ids_.assign((size_t)width * height, HVRT_MISS); else hit_ids_.clear();
     uint64_t counters[2] = { 0, 0 };
     LOG_INFO("[{}] Rendering {}x{} image...", getMethodName(), width, height);
-    ck(scene_->handle(), hvrt_render(scene_->handle(), &fr, width, height, 1, 0, &frame[0].x, hit_ids_.data(), nullptr, counters),
-       "hvrt_render");
+    ck(scene_->handle(), hvrt_render(scene_->handle(), &fr, width, height, 1, 0, &frame[0].x,
+                                     keep_hit_ids_ ? hit_ids_.data() : nullptr, nullptr, counters), "hvrt_render");
     voxels_ = counters[0];
     tests_ = counters[1];
-    size_t hits = 0;
-    for (unsigned int h : hit_ids_) hits += h != HVRT_MISS;
+    uint64_t hits = 0;
+    ck(scene_->handle(), hvrt_last_hit_count(scene_->handle(), &hits), "hvrt_last_hit_count");
     const double total = (double)width * height;
     // same statistics lines as OctreeLikeRayTracer.cpp:57-65 (counted once per ray, not twice)
     LOG_INFO("[{}] Rendering complete! kernel {:.3f} ms", getMethodName(), scene_->lastRenderMs());

@@ -75,10 +75,14 @@ public:
     std::vector<cg_datastructures::RayHit> traceRays(const std::vector<cg_datastructures::Ray>& rays);
     unsigned long long voxelsTraversed() const { return voxels_; }
     unsigned long long triangleTests() const { return tests_; }
+    // per-pixel hit triangle ids of the last render() (HVRT_MISS = 0xFFFFFFFF for none): fetched only after
+    // keepHitIds(true); renderViewsRgb8 always keeps those of its last view
+    void keepHitIds(bool on) { keep_hit_ids_ = on; }
     const std::vector<unsigned int>& lastHitIds() const { return hit_ids_; }
 
 private:
     std::shared_ptr<HipScene> scene_;
     unsigned long long voxels_ = 0, tests_ = 0;
     std::vector<unsigned int> hit_ids_;
+    bool keep_hit_ids_ = false;
 };

@@ -119,6 +119,7 @@ std::unique_ptr<IRayTracer> TraceImages::createRayTracer(VoxelGrid& voxelGrid, R
 void TraceImages::renderAndSave(Loaded& l, const Camera& cam, const std::string& filename, RayTracingMethod) {
     HipVoxelRayTracer tracer(l.scene);
     tracer.setNearestHit(nearestHit);
+    tracer.keepHitIds(keepHitIds);
     auto t0 = std::chrono::steady_clock::now();
     lastPixels = tracer.render(cam, imageWidth, imageHeight);
     lastHitIds = tracer.lastHitIds();

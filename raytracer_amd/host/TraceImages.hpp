@@ -42,7 +42,8 @@ public:
     bool nearestHit = false;
     // last frame rendered (for callers / tests that want the pixels, not the file)
     std::vector<cg_datastructures::Vec3> lastPixels;
-    std::vector<unsigned int> lastHitIds;
+    std::vector<unsigned int> lastHitIds;   // of the last image; single-view renders fetch them only if keepHitIds
+    bool keepHitIds = false;
     bool lastOk = false;
 
     // the factory seam (TraceImages.cpp:464-484), public here so that tests can reach it

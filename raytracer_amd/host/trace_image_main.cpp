@@ -70,6 +70,7 @@ int main(int argc, char** argv) {
             ti.imageHeight = H;
             ti.outputDirectory = outdir;
             ti.nearestHit = nearest;
+            ti.keepHitIds = !dump.empty();      // the raw dump holds the hit-id image
             if (multiview) ti.TraceImageMultiView(in, out, method);
             else ti.TraceImage(in, out, method);
             if (ti.lastOk && !dump.empty()) {

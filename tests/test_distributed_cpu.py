@@ -60,6 +60,15 @@ def _worker(rank, world, port, tile_rows, W, H, out_dir):
         for p in range(world):                             # reassembly (hvrt_assemble_parts_device on the GPU)
             pr = part.global_rows(p)
             frame[pr] = gathered[p, :len(pr)].numpy()
+        # the same exchange moving 8-bit pixels (what the GPU path sends by default: quantised before the collective
+        # with ImageSaver.h's rule, 3 bytes per pixel instead of 12)
+        q = lambda a: np.clip(a * np.float32(255.0), 0, 255).astype(np.int32).astype(np.uint8)
+        gathered8 = gather_parts(torch.from_numpy(q(slab.numpy())))
+        frame8 = np.zeros((H, W, 3), np.uint8)
+        for p in range(world):
+            pr = part.global_rows(p)
+            frame8[pr] = gathered8[p, :len(pr)].numpy()
+        assert gathered8.dtype == torch.uint8 and np.array_equal(frame8, q(frame))
         if rank == 0:
             full, _, _, _ = sc.render(fr, W, H, threads=2)
             np.save(os.path.join(out_dir, "ok.npy"), np.array([np.array_equal(frame.view(np.uint32), full.view(np.uint32))]))

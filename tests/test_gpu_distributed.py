@@ -305,3 +305,46 @@ def test_two_processes_share_the_gpu_over_gloo(tmp_path):
     s.close()
     mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert np.load(tmp_path / "ok.npy")[0] == 1
+
+
+@pytest.mark.parametrize("world,tile_rows,H", [(2, 16, 150), (8, 16, 130)])
+def test_render_frames_exchanging_8_bit_pixels(ctx, monkeypatch, world, tile_rows, H):
+    """rgb8=True: every rank quantises its slab on the device (ImageSaver.h's rule) BEFORE the collective, 3 bytes
+    per pixel cross the wire instead of 12, and the reassembled 8-bit frame is the 1-GPU float frame quantised
+    (SURVEY.md 8f row 3).  Stand-in all_gather as above; also the batch pipeline's buffers in this mode."""
+    import torch
+    from raytracer_amd import distributed as D
+    from test_gpu_render import _quantise_ref
+    tris, mn, mx, vs, cam = _scene(ctx, 16, 24)
+    W = 200
+    dev = torch.device("cuda:0")
+    want = _quantise_ref(ctx.render(cam, W, H)[0])
+    part = D.Partition(H, tile_rows, world)
+    slabs8 = {}
+    for p in range(world):
+        s = torch.zeros((part.slab_rows, W, 3), dtype=torch.float32, device=dev)
+        s8 = torch.zeros((part.slab_rows, W, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.render_part_device(cam, W, H, 1, 0, tile_rows, p, world, d_rgb=s.data_ptr())
+        ctx.quantise_rgb8_device(s.data_ptr(), s.numel(), s8.data_ptr())
+        ctx.synchronize()
+        slabs8[p] = s8
+    for rank in (0, world - 1):
+        seen = []
+
+        def fake_all_gather(out, inp, group=None, async_op=False, _rank=rank):
+            seen.append((inp.dtype, inp.numel()))
+            for p in range(world):
+                out[p].copy_(inp if p == _rank else slabs8[p])
+
+        monkeypatch.setattr(D.dist, "all_gather_into_tensor", fake_all_gather)
+        dr = D.DistributedRenderer(ctx, rank, world, dev, tile_rows=tile_rows)
+        dr.alloc(W, H, n_frames=1, rgb8=True)
+        frames = dr.render_frames([cam])
+        torch.cuda.synchronize()
+        assert seen == [(torch.uint8, part.slab_rows * W * 3)]          # 3 bytes per pixel on the wire
+        assert frames.dtype == torch.uint8 and np.array_equal(frames[0].cpu().numpy(), want), f"rank {rank}"
+    with pytest.raises(ValueError):
+        D.DistributedRenderer(ctx, 0, world, dev, tile_rows=tile_rows).alloc(201, H, rgb8=True)
+    with pytest.raises(capi.HvrtError):          # a 3-byte row that is not a whole number of words
+        ctx.assemble_parts_device(slabs8[0].data_ptr(), 201, H, tile_rows, world, part.slab_rows, 3, slabs8[0].data_ptr())
