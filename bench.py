@@ -1,17 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py -- primary-ray throughput at 4K on BASELINE.json config 2, plus voxel-grid build time.
+"""bench.py -- primary-ray throughput at 4K on BASELINE.json config 2 (default), the other configs on request.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|small] [--scaling weak|strong]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Workload (config.workload = "c2"): libm-free cube-sphere, 1 002 252 triangles, 256^3 grid, 3840x2160
-primary rays, the reference's front camera rule (TraceImages.cpp:125-146) with aspect = W/H, 1 spp,
-pixel-corner sampling.  A step = one pass of the hot path over one batch of rays:
-  N = 1 : the traversal kernel renders one 4K frame (rgb + hit id + t written) from the HBM-resident scene.
-  N > 1 : weak scaling -- a batch of N frames; every frame's 16-row tiles are interleaved over the N ranks,
-          each rank traces one frame's worth of rays per step, every frame is all-gathered with RCCL
-          (overlapped with the next frame's traversal) and reassembled.  value = all rays / max-over-ranks time.
-Output: ONE JSON line on rank 0 (metric / roofline / cpu_baseline as DESIGN.md section "Measurement" defines).
+Workloads (config.workload; synthetic, libm-free generators of raytracer_amd/meshgen.py):
+  c2  cube-sphere, 1 002 252 triangles, 256^3, 3840x2160, 1 spp            -- the configuration the metric is quoted on
+  c3  cube-sphere N=913 (10 002 828 triangles) + a 2.4 M-triangle patch over 1 % of the surface, 512^3, 3840x2160
+  c4  the c2 scene at 7680x4320, 16 jittered samples per pixel (seed 1)
+  c5  voxel-build stress: cube-sphere N=2041 (49 988 172 triangles) into 1024^3; build only (metric: build ms)
+  small  config-1-shaped plumbing case (40 368 triangles, 50^3, 800x600)
+Camera: the reference's front rule (TraceImages.cpp:125-146) with aspect = W/H, pixel-corner sampling.
+
+A step = one pass of the hot path over one batch of rays:
+  N = 1          the traversal kernel renders one frame (rgb + hit id + t written) from the HBM-resident scene.
+  N > 1, weak    (default) a batch of N frames; every frame's 16-row tiles are interleaved over the N ranks, each
+                 rank traces one frame's worth of rays per step, ONE RCCL all_to_all of 8-bit slabs hands frame f to
+                 rank f (overlapped with the next batch's traversal), which reassembles it.
+  N > 1, strong  one frame per step, its row tiles interleaved over the N ranks, RCCL all_gather of the 8-bit slabs,
+                 reassembled on every rank (config 4's "row tiles partitioned across 8 MI355X").
+value = all rays of the K steps / max-over-ranks wall time.
+Output: ONE JSON line on rank 0 (metric / roofline / cpu_baseline as DESIGN.md section 6 defines them).
 """
 import argparse
 import json
@@ -26,19 +35,27 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 WORKLOADS = {
-    # name: (cube-sphere n, grid, W, H)
-    "c2": (289, 256, 3840, 2160),
-    "small": (58, 50, 800, 600),          # config-1-shaped plumbing case (not a bench line)
+    # name: (mesh, grid, W, H, spp, seed)
+    "c2": (("cube_sphere", 289), 256, 3840, 2160, 1, 0),
+    "c3": (("skewed_statue", 913, 1100), 512, 3840, 2160, 1, 0),
+    "c4": (("cube_sphere", 289), 256, 7680, 4320, 16, 1),
+    "c5": (("cube_sphere", 2041), 1024, 0, 0, 0, 0),
+    "small": (("cube_sphere", 58), 50, 800, 600, 1, 0),          # config-1-shaped plumbing case (not a bench line)
 }
 
 
-def cpu_baseline(tris, g, mn, vs, off, idx, cam, W, H, n_rays_target=8.3e6):
+def make_mesh(spec):
+    from raytracer_amd import meshgen
+    return getattr(meshgen, spec[0])(*spec[1:])
+
+
+def cpu_baseline(tris, g, mn, vs, off, idx, cam, W, H, spp, seed, n_rays_target=8.3e6):
     """Times the oracle (our CPU port of the reference path, kind 'port') on a bounded sample of the SAME
     frame: evenly spaced rows, all host threads of this box's CPU share."""
     import oracle
     threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     sc = oracle.OracleScene(tris, g, g, g, mn, vs, off, idx)
-    n_rows = min(H, max(threads, int(n_rays_target // W)))
+    n_rows = min(H, max(threads, int(n_rays_target // (W * spp))))
     rows = np.linspace(0, H - 1, n_rows).astype(int)
     from concurrent.futures import ThreadPoolExecutor
     import ctypes as C
@@ -47,19 +64,19 @@ def cpu_baseline(tris, g, mn, vs, off, idx, cam, W, H, n_rays_target=8.3e6):
 
     def work(k):
         for y in rows[k::threads]:
-            oracle.lib().orc_render_rows(C.byref(sc.c), C.byref(f), W, H, int(y), int(y) + 1, 1, C.c_uint32(0),
+            oracle.lib().orc_render_rows(C.byref(sc.c), C.byref(f), W, H, int(y), int(y) + 1, spp, C.c_uint32(seed),
                                          None, None, None, C.c_void_p(cnts[k].ctypes.data))
 
     t0 = time.perf_counter()
     with ThreadPoolExecutor(threads) as ex:
         list(ex.map(work, range(threads)))
     dt = time.perf_counter() - t0
-    rays = len(rows) * W
+    rays = len(rows) * W * spp
     # one core, every 16th of those rows (SURVEY 8d asks for both)
     rows1 = rows[::16]
     t2 = time.perf_counter()
     for y in rows1:
-        oracle.lib().orc_render_rows(C.byref(sc.c), C.byref(f), W, H, int(y), int(y) + 1, 1, C.c_uint32(0),
+        oracle.lib().orc_render_rows(C.byref(sc.c), C.byref(f), W, H, int(y), int(y) + 1, spp, C.c_uint32(seed),
                                      None, None, None, C.c_void_p(cnts[0].ctypes.data))
     dt1 = time.perf_counter() - t2
     # voxel build on one core (flat CSR port of SceneCreator.cpp:197-281)
@@ -67,26 +84,68 @@ def cpu_baseline(tris, g, mn, vs, off, idx, cam, W, H, n_rays_target=8.3e6):
     oracle.voxelize(tris, g, g, g, mn, vs)
     bt = time.perf_counter() - t1
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"{len(rows)} evenly spaced rows of the same {W}x{H} frame ({rays} rays, {dt:.2f} s); "
-                      f"oracle/cpu_ref.c, one trace per pixel",
-            "value_1core": len(rows1) * W / dt1 / 1e6,   # Mrays/s, one thread, every 16th row of the sample
+            "sample": f"{len(rows)} evenly spaced rows of the same {W}x{H} frame at {spp} spp ({rays} rays, {dt:.2f} s); "
+                      f"oracle/cpu_ref.c, one trace per sample",
+            "value_1core": len(rows1) * W * spp / dt1 / 1e6,   # Mrays/s, one thread, every 16th row of the sample
             "build_ms_1core": bt * 1e3 / 2.0,   # voxelize() runs the count pass twice (sizing + fill)
-            }
+            "reference_itself": "the reference's own OctreeLikeRayTracer does not compile in this image (spdlog); measured by "
+                                "the survey session on one core of the authoring container: 0.07-0.09 Mrays/s on a 1.0 M-triangle "
+                                "sphere at 256^3, build 1.9-2.1 s (SURVEY.md section 6)"}
+
+
+def load_profile(workload):
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tp)).get(workload, {})
+    except Exception:
+        return {}
+
+
+def render_roofline(prof, k_ms, rays, bytes_per_ray):
+    """What binds k_render, as a fraction <= 1 of that resource, plus the HBM yardstick north_star asks for.
+    Everything that is not measured live comes from profiles/traffic.json (which names the counter files)."""
+    requested = bytes_per_ray * rays                       # bytes the REFERENCE algorithm asks for, per launch
+    out = {"kernel": "k_render", "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
+           "requested_GBps": requested / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0}
+    traffic = prof.get("k_render_hbm_bytes_per_launch")
+    out["traffic"] = traffic
+    if traffic:
+        out["hbm_frac"] = traffic / (k_ms * 1e-3) / 8e12    # counter-based: HBM is nowhere near binding
+        out["reuse_factor"] = requested / traffic           # requested bytes served from cache or never asked for
+    cands = {k: prof[k] for k in ("valu_issue_frac", "vmem_return_frac", "salu_issue_frac", "lds_frac") if k in prof}
+    if cands:
+        bound = max(cands, key=cands.get)
+        out.update({"bound": bound.replace("_frac", ""), "achieved": cands[bound], "peak": 1.0,
+                    "unit": "busy clocks of the binding unit per kernel clock", "frac": cands[bound]})
+        out["candidates"] = cands
+        for k in ("valu_insts_per_launch", "valu_clocks_per_inst", "vector_loads_per_launch", "kernel_cycles", "profiled_kernel_ms",
+                  "l2_hit_rate", "source"):
+            if k in prof:
+                out[k] = prof[k]
+    else:
+        # no profile installed for this workload: the HBM yardstick alone (requested bytes against the 8 TB/s peak)
+        out.update({"bound": "hbm", "achieved": out["requested_GBps"], "peak": 8000.0, "unit": "GB/s",
+                    "frac": None, "note": "no counter profile for this workload under profiles/; requested (algorithmic) "
+                                          "bytes are mostly served from cache, so their rate is not a fraction of the HBM peak"})
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"c4": 5, "c5": 5}.get(args.workload, 20)
 
     import torch
     import torch.distributed as dist
     import raytracer_amd as ra
-    from raytracer_amd import capi, meshgen
+    from raytracer_amd import capi
     from raytracer_amd.distributed import DistributedRenderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,40 +157,19 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    rccl = {"world_size": 1, "backend": None}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                "exchange": "rgb8 slabs (3 B per pixel), " + ("all_to_all, frame f to rank f" if args.scaling == "weak" else "all_gather, every rank gets the frame")}
 
-    n_sphere, g, W, H = WORKLOADS[args.workload]
+    mesh_spec, g, W, H, spp, seed = WORKLOADS[args.workload]
     ctx = ra.Context(local_rank)
     dr = DistributedRenderer(ctx, rank, world, device, tile_rows=16)
-    tris = meshgen.cube_sphere(n_sphere) if rank == 0 else None
+    tris = make_mesh(mesh_spec) if rank == 0 else None
     mn, mx, vs3 = dr.replicate_scene(tris, (g, g, g))
     info = ctx.grid_info()
-    pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
-    cam = capi.make_camera_frame(pos, la, up, fov, asp)
-
-    # ---- voxel-grid build time (rank 0's GPU; mesh resident in HBM) -------------------------------
-    build_ms = None
-    if rank == 0:
-        bt = []
-        for _ in range(5):
-            ctx.build_grid(g, g, g, mn, mx, vs3)
-            bt.append(ctx.timings().build_total_ms)
-        build_ms = float(np.median(bt))
-        tmb = ctx.timings()
-
-    # ---- per-ray work of this frame (V voxels, T triangle tests) from the kernel's own counters ----
-    rgb_d = torch.empty((H, W, 3), dtype=torch.float32, device=device)
-    hit_d = torch.empty((H, W), dtype=torch.int32, device=device)
-    t_d = torch.empty((H, W), dtype=torch.float32, device=device)
-    cnt_d = torch.zeros(2, dtype=torch.int64, device=device)
-    torch.cuda.synchronize(device)
-    ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), cnt_d.data_ptr())
-    ctx.synchronize()
-    V, T = (cnt_d.cpu().numpy() / float(W * H)).tolist()
-    hit_frac = float((hit_d != -1).float().mean().item())
-    bytes_per_ray = 8.0 * V + 40.0 * T + 12.0 + 8.0          # +8 because hit id and t are written
 
     def barrier():
         if world > 1:
@@ -139,25 +177,138 @@ def main():
         torch.cuda.synchronize(device)
         ctx.synchronize()
 
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl": rccl}
+    scene = {"refs": int(info.n_refs), "occupied_voxels": int(info.n_occupied), "max_list": int(info.max_list)}
+    nvox = g ** 3
+    b_build = 72.0 * info.n_triangles + 12.0 * nvox + 20.0 * info.n_refs
+
+    # ---- voxel-grid build (rank 0's GPU; mesh resident in HBM) --------------------------------------------------------
+    def timed_builds(n):
+        bt, last = [], None
+        for _ in range(n):
+            ctx.build_grid(g, g, g, mn, mx, vs3)
+            last = ctx.timings()
+            bt.append(last.build_total_ms)
+        return bt, last
+
+    def build_report(bt, tmb):
+        ms = float(np.median(bt))
+        csr = tmb.build_count_ms + tmb.build_scan_ms + tmb.build_fill_ms + tmb.build_sort_ms
+        prof = load_profile(args.workload)
+        r = {"bound": "hbm", "achieved": b_build / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+             "frac": b_build / (ms * 1e-3) / 8e12, "algorithmic_bytes": b_build,
+             "csr_ms": csr, "accel_ms": tmb.build_expand_ms,
+             "csr_frac": b_build / (csr * 1e-3) / 8e12,
+             "traffic": prof.get("build_hbm_bytes"), "traffic_source": prof.get("build_source"),
+             "note": "B_build = 72 T + 12 Nvox + 20 Nrefs prices the CSR (count, scan, fill, order); accel_ms is the derived "
+                     "acceleration data (distance field, face bits, per-reference records), which B_build does not contain"}
+        brk = {"count": tmb.build_count_ms, "scan": tmb.build_scan_ms, "fill": tmb.build_fill_ms, "sort": tmb.build_sort_ms,
+               "distance_field+face_bits+records": tmb.build_expand_ms}
+        return ms, brk, r
+
+    if args.workload == "c5":
+        # build only: a step is one build of the resident 50 M-triangle mesh into 1024^3
+        if world > 1:
+            raise SystemExit("c5 is a one-GPU workload (the voxel build does not shard: replicas only)")
+        timed_builds(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        bt, tmb = timed_builds(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        ms, brk, rb = build_report(bt, tmb)
+        out = dict(base, metric="voxel-grid build ms", value=dt / args.steps * 1e3, unit="ms", ms_per_step=dt / args.steps * 1e3,
+                   higher_is_better=False, scaling="weak",
+                   config={"workload": "c5", "mesh": "cube-sphere n=2041", "triangles": int(info.n_triangles), "grid": [g, g, g],
+                           "step": "one hvrt_build_grid of the HBM-resident mesh (CSR + derived acceleration data)"},
+                   voxel_build_ms=ms, voxel_build_breakdown_ms=brk, scene=scene, roofline=rb)
+        if not args.no_cpu_baseline:
+            import oracle
+            sub = tris[: tris.shape[0] // 16]                        # a bounded sample: 1/16 of the triangles, same grid
+            t1 = time.perf_counter()
+            oracle.voxelize(sub, g, g, g, mn, float(vs3[0]))
+            bt1 = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": bt1 * 1e3 / 2.0 * 16, "unit": "ms (extrapolated x16)", "cores": 1, "kind": "port",
+                                   "sample": f"oracle/cpu_ref.c count+fill of the first 1/16 of the triangles ({sub.shape[0]}) into the same "
+                                             f"1024^3 grid took {bt1 / 2.0:.2f} s; the reference's own nested-vector build cannot hold 1024^3 in 64 GB"}
+        print(json.dumps(out), flush=True)
+        ctx.close()
+        return
+
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
+    cam = capi.make_camera_frame(pos, la, up, fov, asp)
+
+    build_ms = None
+    if rank == 0:
+        bt, tmb = timed_builds(5)
+        build_ms, build_brk, roof_build = build_report(bt, tmb)
+
+    # ---- per-ray work of this frame (V voxels, T triangle tests) from the kernel's own counters; this is also the first
+    # launch of the shape on this context (no tile history): its duration is cold_ms (counting kernel, hence an upper bound)
+    rgb_d = torch.empty((H, W, 3), dtype=torch.float32, device=device)
+    hit_d = torch.empty((H, W), dtype=torch.int32, device=device)
+    t_d = torch.empty((H, W), dtype=torch.float32, device=device)
+    cnt_d = torch.zeros(2, dtype=torch.int64, device=device)
+    torch.cuda.synchronize(device)
+    ctx.render_part_device(cam, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), cnt_d.data_ptr())
+    ctx.synchronize()
+    V, T = (cnt_d.cpu().numpy() / float(W * H * spp)).tolist()
+    hit_frac = float((hit_d != -1).float().mean().item())
+    bytes_per_ray = 8.0 * V + 40.0 * T + (12.0 + 8.0) / spp          # +8 because hit id and t are written
+    scene.update({"voxels_per_ray": V, "tri_tests_per_ray": T, "hit_fraction": hit_frac})
+
+    cold_ms = unordered_ms = None
+    if world == 1:
+        # first launch of a shape (no tile history: the give-up variant + the split kernel behind it), plain kernel
+        ctx.build_grid(g, g, g, mn, mx, vs3)                           # a new grid forgets the history
+        ctx.render_part_device(cam, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
+        ctx.synchronize()
+        cold_ms = float(ctx.timings().render_ms)
+        # the same frame with the use of history switched off (HVRT_TILE_ORDER=0 is read when a context is created)
+        os.environ["HVRT_TILE_ORDER"] = "0"
+        try:
+            ctx2 = ra.Context(local_rank)
+        finally:
+            del os.environ["HVRT_TILE_ORDER"]
+        a, o, i = ctx.device_arrays()
+        ctx2.set_mesh_device(a, info.n_triangles)
+        ctx2.set_grid_csr_device(g, g, g, mn, mx, vs3, o, i, info.n_refs)
+        ms = []
+        for _ in range(4):
+            ctx2.render_part_device(cam, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
+            ctx2.synchronize()
+            ms.append(ctx2.timings().render_ms)
+        unordered_ms = float(np.mean(ms[1:]))
+        ctx2.close()
+
     kernel_ms = []
     if world == 1:
         def step():
-            ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
-        rays_per_step = W * H
+            ctx.render_part_device(cam, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
+        rays_per_step = W * H * spp
+        scaling = "weak"
+    elif args.scaling == "strong":
+        dr.alloc(W, H, n_frames=1, rgb8=True)
+
+        def step():
+            dr.render_frames([cam], spp=spp, seed=seed)
+        rays_per_step = W * H * spp
+        scaling = "strong"
     else:
         # weak scaling: a batch of `world` frames per step; every rank traces its row tiles of every frame
         # (one frame's worth of rays per rank), one all_to_all hands frame f to rank f, which reassembles it.
         # The exchange of batch k overlaps the traversal of batch k+1.
-        dr.alloc_batch(W, H)
+        dr.alloc_batch(W, H, rgb8=True)
         cams = [cam] * world
 
         def step():
-            dr.render_batch(cams)
-        rays_per_step = W * H * world
+            dr.render_batch(cams, spp=spp, seed=seed)
+        rays_per_step = W * H * spp * world
+        scaling = "weak"
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if world > 1 and scaling == "weak":
         dr.flush()
     barrier()
     t0 = time.perf_counter()
@@ -172,7 +323,8 @@ def main():
     else:
         for _ in range(args.steps):
             step()
-        dr.flush()             # the last batch's exchange + reassembly belong to the timed region
+        if scaling == "weak":
+            dr.flush()             # the last batch's exchange + reassembly belong to the timed region
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -180,53 +332,46 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- the interface the reference calls (IRayTracer::render -> hvrt_render: host buffers, PCIe included) -----------
+    interface_ms = None
+    if world == 1 and rank == 0 and args.workload in ("c2", "small"):
+        host_rgb = np.ones((H, W, 3), np.float32)           # touched pages, like a caller's zero-filled std::vector<Vec3>
+        import ctypes as C
+        lib = capi.load_library()
+        ts = []
+        for _ in range(5):
+            t1 = time.perf_counter()
+            rc = lib.hvrt_render(ctx._h, C.byref(cam), W, H, spp, seed, host_rgb.ctypes.data_as(C.c_void_p), None, None, None)
+            ts.append((time.perf_counter() - t1) * 1e3)
+            assert rc == 0
+        interface_ms = {"rgb_first_call": ts[0], "rgb_warm": float(min(ts[1:])),
+                        "what": "hvrt_render(rgb only) into the caller's pageable buffer, what HipVoxelRayTracer::render does; "
+                                "PCIe-inclusive, never `value`"}
+
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = rays_per_step / (ms_per_step * 1e-3) / 1e6
-        out = {
-            "metric": "primary Mrays/s (node) at 4K", "value": value, "unit": "Mrays/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "mesh": f"cube-sphere n={n_sphere}", "triangles": int(info.n_triangles),
-                       "grid": [g, g, g], "image": [W, H], "spp": 1, "camera": "reference front rule, aspect=W/H",
-                       "frames_per_step": world, "tile_rows": 16,
-                       "outputs": "rgb+hit_id+t" if world == 1 else "rgb; all_to_all of row-tile slabs, frame f reassembled on rank f"},
-            "voxel_build_ms": build_ms,
-            "voxel_build_breakdown_ms": {"count": tmb.build_count_ms, "scan": tmb.build_scan_ms,
-                                         "fill": tmb.build_fill_ms, "sort": tmb.build_sort_ms,
-                                         "distance_field+face_bits+records": tmb.build_expand_ms},
-            "scene": {"refs": int(info.n_refs), "occupied_voxels": int(info.n_occupied), "max_list": int(info.max_list),
-                      "voxels_per_ray": V, "tri_tests_per_ray": T, "hit_fraction": hit_frac},
-        }
+        out = dict(base, metric="primary Mrays/s (node) at 4K" if args.workload == "c2" else "primary Mrays/s (node)",
+                   value=value, unit="Mrays/s", ms_per_step=ms_per_step, higher_is_better=True, scaling=scaling,
+                   config={"workload": args.workload, "mesh": " ".join(str(v) for v in mesh_spec), "triangles": int(info.n_triangles),
+                           "grid": [g, g, g], "image": [W, H], "spp": spp, "camera": "reference front rule, aspect=W/H",
+                           "frames_per_step": world if scaling == "weak" else 1, "tile_rows": 16,
+                           "outputs": "rgb+hit_id+t" if world == 1 else "rgb, exchanged as 8-bit slabs"},
+                   voxel_build_ms=build_ms, voxel_build_breakdown_ms=build_brk, scene=scene)
         if kernel_ms:
             k_ms = float(np.mean(kernel_ms))
-            achieved = bytes_per_ray * W * H / (k_ms * 1e-3) / 1e9
-            traffic, prof = None, {}
-            tp = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tp):
-                try:
-                    prof = json.load(open(tp)).get(args.workload, {})
-                    traffic = prof.get("k_render_hbm_bytes_per_launch")
-                except Exception:
-                    prof, traffic = {}, None
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                               "frac": achieved / 8000.0, "traffic": traffic, "kernel": "k_render",
-                               "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
-                               "note": "algorithmic (requested) bytes 8V+40T+20 per ray; >1 means the bytes are served "
-                                       "from cache or never requested; what binds the kernel is per-CU: VALU issue and the vector-load "
-                                       "return path, both saturated (see binding)",
-                               "binding": {k: prof[k] for k in ("valu_issue_frac", "salu_issue_frac", "td_busy_frac", "ta_busy_frac", "l2_hit_rate",
-                                                                "busy_source") if k in prof}}
-            nvox = g ** 3
-            b_build = 72.0 * info.n_triangles + 12.0 * nvox + 20.0 * info.n_refs
-            out["roofline_build"] = {"bound": "hbm", "achieved": b_build / (build_ms * 1e-3) / 1e9, "peak": 8000.0,
-                                     "unit": "GB/s", "frac": b_build / (build_ms * 1e-3) / 1e9 / 8000.0,
-                                     "algorithmic_bytes": b_build}
+            out["roofline"] = render_roofline(load_profile(args.workload), k_ms, W * H * spp, bytes_per_ray)
+            out["cold_ms"] = cold_ms                     # first launch of the shape, no tile history
+            out["unordered_ms"] = unordered_ms           # HVRT_TILE_ORDER=0: every launch like a first one
+            out["unordered_Mrays_s"] = W * H * spp / (unordered_ms * 1e-3) / 1e6 if unordered_ms else None
+        out["roofline_build"] = roof_build
+        if interface_ms:
+            out["interface_ms"] = interface_ms
         if world == 1 and not args.no_cpu_baseline:
             off, idx = ctx.get_csr()
             if tris is None:
-                tris = meshgen.cube_sphere(n_sphere)
-            out["cpu_baseline"] = cpu_baseline(tris, g, mn, float(vs3[0]), off, idx, cam, W, H)
+                tris = make_mesh(mesh_spec)
+            out["cpu_baseline"] = cpu_baseline(tris, g, mn, float(vs3[0]), off, idx, cam, W, H, spp, seed)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,10 +18,10 @@
 #define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
 
 enum Op { MUL_F32, ADD_F32, MUL_SGPR, CNDMASK, CMP_F32, READLANE, RCP_F32, MAD_U64, FMA_F32, PK_MUL_F32, ADD_U32,
-          CNDMASK_SGPR, CNDMASK_DST, CNDMASK_E64_VCC, CNDMASK_INT, CNDMASK_VCMP, CNDMASK_SALU, CNDMASK_VCMP4, SUBBREV_SALU, MOV_B32, SUBBREV, ADD3_U32, ALIGNBIT, CMP_VCC, MOV_DPP, N_OPS };
+          CNDMASK_SGPR, CNDMASK_DST, CNDMASK_E64_VCC, CNDMASK_INT, CNDMASK_VCMP, CNDMASK_SALU, CNDMASK_VCMP4, SUBBREV_SALU, MUL_LO_U32, MUL_HI_U32, CVT_F32_I32, LSHL_ADD_U32, SQRT_F32, DIV_SCALE, MOV_B32, SUBBREV, ADD3_U32, ALIGNBIT, CMP_VCC, MOV_DPP, N_OPS };
 static const char* op_name[N_OPS] = { "v_mul_f32 v,v,v", "v_add_f32 v,v,v", "v_mul_f32 v,s,v", "v_cndmask_b32 a,a,c,vcc", "v_cmp_lt_f32 (sgpr pair out)",
                                        "v_readlane_b32 s,v,imm", "v_rcp_f32", "v_mad_u64_u32", "v_fma_f32", "v_pk_mul_f32", "v_add_u32",
-                                       "v_cndmask_b32 a,a,c,s[20:21]", "v_cndmask_b32 t,a,c,vcc", "v_cndmask_b32_e64 a,a,c,vcc", "v_cndmask_b32 a,a,c,vcc (ints)", "v_cmp vcc + v_cndmask vcc (pair)", "s_mov vcc + v_cndmask vcc (pair)", "v_cmp vcc + 3 v_cndmask vcc (four)", "s_mov vcc + v_subbrev vcc (pair)", "v_mov_b32", "v_subbrev_co_u32 (vcc in/out)",
+                                       "v_cndmask_b32 a,a,c,s[20:21]", "v_cndmask_b32 t,a,c,vcc", "v_cndmask_b32_e64 a,a,c,vcc", "v_cndmask_b32 a,a,c,vcc (ints)", "v_cmp vcc + v_cndmask vcc (pair)", "s_mov vcc + v_cndmask vcc (pair)", "v_cmp vcc + 3 v_cndmask vcc (four)", "s_mov vcc + v_subbrev vcc (pair)", "v_mul_lo_u32", "v_mul_hi_u32", "v_cvt_f32_i32", "v_lshl_add_u32", "v_sqrt_f32", "v_div_scale_f32", "v_mov_b32", "v_subbrev_co_u32 (vcc in/out)",
                                        "v_add3_u32", "v_alignbit_b32", "v_cmp_lt_f32 (vcc out)", "v_mov_b32 dpp quad_perm" };
 
 template <int OP>
@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256) void k(int iters, float seed, unsigned long lo
         if (OP == CNDMASK_SALU) asm volatile("s_mov_b64 vcc, s[20:21]\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c) : "vcc"); \
         if (OP == CNDMASK_VCMP4) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(c) : "vcc"); \
         if (OP == SUBBREV_SALU) asm volatile("s_mov_b64 vcc, s[20:21]\n v_subbrev_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i]) :: "vcc"); \
+        if (OP == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(ai[i]) : "v"(ci)); \
+        if (OP == MUL_HI_U32) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(ai[i]) : "v"(ci)); \
+        if (OP == CVT_F32_I32) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(a[i]) : "v"(ci)); \
+        if (OP == LSHL_ADD_U32) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(ai[i]) : "v"(ci)); \
+        if (OP == SQRT_F32) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i])); \
+        if (OP == DIV_SCALE) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(c) : "vcc"); \
         if (OP == MOV_B32) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(c)); \
         if (OP == SUBBREV) asm volatile("v_subbrev_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i]) :: "vcc"); \
         if (OP == ADD3_U32) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(a[i]) : "v"(c)); \
@@ -122,6 +128,6 @@ int main() {
     double ghz = 0;
 #define ROW(OP) { printf("%-32s", op_name[OP]); for (int w : ws) printf("%8.2f", run<OP>(cus, w, iters, d_out, h, &ghz)); printf("   (%.2f GHz)\n", ghz); }
     ROW(MUL_F32) ROW(ADD_F32) ROW(FMA_F32) ROW(MUL_SGPR) ROW(ADD_U32) ROW(ADD3_U32) ROW(ALIGNBIT) ROW(MOV_B32) ROW(MOV_DPP)
-    ROW(CNDMASK) ROW(CNDMASK_SGPR) ROW(CNDMASK_DST) ROW(CNDMASK_E64_VCC) ROW(CNDMASK_INT) ROW(CNDMASK_VCMP) ROW(CNDMASK_SALU) ROW(CNDMASK_VCMP4) ROW(SUBBREV_SALU) ROW(SUBBREV) ROW(CMP_VCC) ROW(CMP_F32) ROW(READLANE) ROW(RCP_F32) ROW(MAD_U64) ROW(PK_MUL_F32)
+    ROW(CNDMASK) ROW(CNDMASK_SGPR) ROW(CNDMASK_DST) ROW(CNDMASK_E64_VCC) ROW(CNDMASK_INT) ROW(CNDMASK_VCMP) ROW(CNDMASK_SALU) ROW(CNDMASK_VCMP4) ROW(SUBBREV_SALU) ROW(MUL_LO_U32) ROW(MUL_HI_U32) ROW(CVT_F32_I32) ROW(LSHL_ADD_U32) ROW(SQRT_F32) ROW(DIV_SCALE) ROW(SUBBREV) ROW(CMP_VCC) ROW(CMP_F32) ROW(READLANE) ROW(RCP_F32) ROW(MAD_U64) ROW(PK_MUL_F32)
     return 0;
 }
