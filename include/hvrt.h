@@ -114,6 +114,15 @@ int hvrt_synchronize(hvrt_ctx* ctx);
 int hvrt_set_mode(hvrt_ctx* ctx, int mode);
 int hvrt_get_timings(const hvrt_ctx* ctx, hvrt_timings* out);
 
+/* Callers that only want the voxel grid itself (the CSR that replaces VoxelGrid::voxels, SceneCreator.cpp:197-281)
+ * can keep libhvrt's own derived acceleration data -- empty-space distance field, face bits, per-reference records,
+ * none of which the reference has -- out of hvrt_build_grid / hvrt_set_grid_csr*: with on != 0 those calls return once
+ * the CSR stands, and the derived data is built by the first render / trace / hvrt_get_distance_field, or by
+ * hvrt_finish_accel (hvrt_timings.build_expand_ms is then that call's time).  Default: off (built with the grid).
+ * No counterpart in the reference (its grid has no derived data). */
+int hvrt_set_deferred_accel(hvrt_ctx* ctx, int on);
+int hvrt_finish_accel(hvrt_ctx* ctx);
+
 /* ---- mesh ---------------------------------------------------------------------------------- */
 
 /* Replaces: buildTriangleList's output `std::vector<Triangle>` (SceneCreator.cpp:129-170,

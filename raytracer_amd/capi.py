@@ -25,6 +25,7 @@ SYMBOLS = [
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc", "hvrt_last_hit_count",
+    "hvrt_set_deferred_accel", "hvrt_finish_accel",
 ]
 
 
@@ -108,6 +109,8 @@ def load_library() -> C.CDLL:
                                             C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_render_part_device_noalloc.argtypes = lib.hvrt_render_part_device.argtypes
     lib.hvrt_last_hit_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.hvrt_set_deferred_accel.argtypes = [vp, C.c_int]
+    lib.hvrt_finish_accel.argtypes = [vp]
     lib.hvrt_render_batch_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                                   C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_quantise_rgb8_device.argtypes = [vp, vp, C.c_uint64, vp]
@@ -285,6 +288,13 @@ class Context:
     def set_mode(self, mode: int):
         """0 = the reference's traversal (default), 1 = nearest-hit mode."""
         self._ck(self._lib.hvrt_set_mode(self._h, mode))
+
+    def set_deferred_accel(self, on: bool):
+        """Keep libhvrt's derived acceleration data out of build_grid / set_grid_csr (built at first use instead)."""
+        self._ck(self._lib.hvrt_set_deferred_accel(self._h, 1 if on else 0))
+
+    def finish_accel(self):
+        self._ck(self._lib.hvrt_finish_accel(self._h))
 
     def synchronize(self):
         self._ck(self._lib.hvrt_synchronize(self._h))

@@ -61,13 +61,19 @@ struct hvrt_ctx {
 
     // build scratch
     uint32_t* ranges = nullptr;   uint64_t ranges_capacity = 0;
-    uint64_t* block_sums = nullptr; uint64_t block_sums_capacity = 0;
+    uint32_t* cnt16 = nullptr;    uint64_t cnt16_capacity = 0;      // 16-bit counters of the count pass, two per word
+    bool narrow_counters = true;   // HVRT_BUILD_NARROW=0; cleared for good once a list of this context outgrew 16 bits
     uint32_t* occ_bits = nullptr; uint64_t occ_bits_capacity = 0;   // one bit per voxel, left by the scan for the distance field
     bool occ_bits_valid = false;
-    uint64_t* stats = nullptr;     // 8 x u64
+    uint64_t* stats = nullptr;     // the build statistics block (hvrt_internal.hpp: stats | vol_sums | scan status | aux)
+    uint64_t stats_capacity = 0;
     uint32_t* long_queue = nullptr; uint64_t long_queue_capacity = 0;
     uint32_t* fill_scratch = nullptr; uint64_t fill_scratch_capacity = 0;  // unsorted ids | voxel of each entry
-    const uint32_t* vox_of = nullptr;  // valid between fill and the end of hvrt_build_grid
+    const uint32_t* vox_of = nullptr;  // valid between fill and the end of hvrt_build_grid (or until deferred data is built)
+    bool reuse_arrays = true;      // HVRT_BUILD_REUSE=0: every build waits for the reference count and sizes its arrays
+    bool defer_accel = false;      // hvrt_set_deferred_accel
+    bool accel_pending = false;    // the CSR is final, the derived data is not built yet
+    bool accel_built_here = false; // whether the pending data belongs to a grid built here (ranges / vox_of usable)
     float* bounds_v = nullptr; uint64_t* bounds_i = nullptr; float* bounds_out = nullptr;
 
     // render scratch
@@ -264,9 +270,18 @@ SceneDev scene_of(const hvrt_ctx* c) {
     return s;
 }
 
-int require_scene(hvrt_ctx* c) {
+int finish_accel(hvrt_ctx* c);
+
+// may_allocate = false: the caller promised not to allocate (hvrt_render_part_device_noalloc); derived data that was
+// deferred must then have been built already (hvrt_finish_accel)
+int require_scene(hvrt_ctx* c, bool may_allocate = true) {
     if (!c->n_tris && !c->tri_rec) return fail(c, HVRT_ERR_INVALID, "no mesh: call hvrt_set_mesh first");
     if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "no grid: call hvrt_build_grid or hvrt_set_grid_csr first");
+    if (c->accel_pending) {
+        if (!may_allocate)
+            return fail(c, HVRT_ERR_INVALID, "the grid's deferred acceleration data is not built yet: call hvrt_finish_accel first");
+        return finish_accel(c);
+    }
     return HVRT_OK;
 }
 
@@ -291,52 +306,78 @@ int join_distance_field(hvrt_ctx* c, hipStream_t s) {
     return HVRT_OK;
 }
 
-int make_ref_records_inner(hvrt_ctx* c, hipStream_t s, bool validate) {
+// rc: the number of entries (known, or still on the device: see RefCount).  With a live count the arrays were sized by
+// an earlier build (ref_capacity_of) and nothing is allocated here.
+int make_ref_records_inner(hvrt_ctx* c, hipStream_t s, bool validate, const RefCount& rc) {
     c->ref_rec_valid = false;
     if (!c->dist_in_flight) if (int r = fork_distance_field(c, s)) return r;
     // face bits: one bit per entry and face, padded by two words so that a 32-entry window read at the
     // last entry stays inside the array
-    c->face_words = (c->n_refs + 63) / 64 * 2 + 2;
-    if (int r = ensure<uint32_t>(c, c->face_bits, c->face_bits_capacity, 6 * c->face_words)) return r;
-    HIP_TRY(c, launch_face_bits(c->indices, c->n_refs, offsets_of(c), c->g, c->n_tris, validate ? nullptr : c->ranges,
-                                validate ? nullptr : c->vox_of, c->face_bits, c->face_words, s));
-    if (c->n_refs == 0) return HVRT_OK;
+    const uint64_t n_alloc = rc.live ? rc.cap : rc.n;
+    if (int r = ensure<uint32_t>(c, c->face_bits, c->face_bits_capacity, 6 * face_words_for(n_alloc))) return r;
+    HIP_TRY(c, launch_face_bits(c->indices, rc, offsets_of(c), c->g, c->n_tris, validate ? nullptr : c->ranges,
+                                validate ? nullptr : c->vox_of, c->face_bits, s));
+    if (n_alloc == 0) return HVRT_OK;
     const bool want = c->inline_records;
     if (want) {
-        if (c->ref_rec_capacity < c->n_refs * 3) {
+        if (c->ref_rec_capacity < n_alloc * 3) {
             if (c->ref_rec) { (void)hipFree(c->ref_rec); c->ref_rec = nullptr; c->ref_rec_capacity = 0; }
             // + 64 float4s: the traversal fetches a list chunk with one 16-byte load per lane of the wave, and the
             // lanes behind the last record of the last list read (and ignore) what follows it
-            hipError_t e = hipMalloc((void**)&c->ref_rec, c->n_refs * 48 + 64 * sizeof(float4));
-            if (e == hipSuccess) c->ref_rec_capacity = c->n_refs * 3;
+            hipError_t e = hipMalloc((void**)&c->ref_rec, n_alloc * 48 + 64 * sizeof(float4));
+            if (e == hipSuccess) c->ref_rec_capacity = n_alloc * 3;
             else { (void)hipGetLastError(); c->ref_rec = nullptr; }   // does not fit: indexed mode
         }
     }
     if (!want || !c->ref_rec) return HVRT_OK;
     HIP_TRY(c, hipMemsetAsync(c->stats + 4, 0, sizeof(uint64_t), s));
-    HIP_TRY(c, launch_expand_records(c->indices, c->n_refs, c->tri_rec, c->n_tris, c->ref_rec, c->stats, s));
-    uint64_t bad = 0;
-    if (validate) {   // ingested CSR: the indices come from the caller
-        HIP_TRY(c, hipMemcpyAsync(&bad, c->stats + 4, sizeof bad, hipMemcpyDeviceToHost, s));
-        HIP_TRY(c, hipStreamSynchronize(s));
-    }
-    if (bad) return fail(c, HVRT_ERR_INVALID, "grid: %llu CSR entries reference a triangle index >= %u",
-                         (unsigned long long)bad, c->n_tris);
+    HIP_TRY(c, launch_expand_records(c->indices, rc, c->tri_rec, c->n_tris, c->ref_rec, c->stats, s));
     c->ref_rec_valid = true;
     return HVRT_OK;
 }
 
 // Builds the derived acceleration data; always rejoins the distance-field stream, whatever the outcome.
-int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate) {
-    const int r = make_ref_records_inner(c, s, validate);
+int make_ref_records(hvrt_ctx* c, hipStream_t s, bool validate, const RefCount& rc) {
+    const int r = make_ref_records_inner(c, s, validate, rc);
     const int j = join_distance_field(c, s);
     return r ? r : j;
+}
+
+// How many CSR entries the arrays left by earlier builds can take (0: some array is missing): a build may then go on
+// past the scan without waiting for the host to read the count back.
+uint64_t ref_capacity_of(const hvrt_ctx* c, bool with_derived_data) {
+    if (!c->indices || !c->fill_scratch || !c->long_queue) return 0;
+    uint64_t cap = c->indices_capacity;
+    auto lower = [&](uint64_t v) { if (v < cap) cap = v; };
+    lower(c->fill_scratch_capacity / 2);
+    lower(c->long_queue_capacity ? (c->long_queue_capacity - 1) * 64 : 0);       // sized total / 64 + 2
+    if (with_derived_data) {
+        lower(c->face_bits && c->face_bits_capacity >= 18 ? (c->face_bits_capacity / 6 - 2) / 2 * 64 : 0);
+        if (c->inline_records) lower(c->ref_rec ? c->ref_rec_capacity / 3 : 0);
+    }
+    return cap > 0xFFFFFFFFull ? 0xFFFFFFFFull : cap;
 }
 
 float ms_between(hipEvent_t a, hipEvent_t b) {
     float ms = 0.0f;
     if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
     return ms;
+}
+
+// The derived data of a grid whose build deferred it (hvrt_set_deferred_accel): distance field, face bits, records.
+int finish_accel(hvrt_ctx* c) {
+    if (!c->accel_pending) return HVRT_OK;
+    hipStream_t s = c->stream;
+    HIP_TRY(c, hipEventRecord(c->ev[5], s));
+    const RefCount rc = { nullptr, c->n_refs, c->n_refs };
+    const int r = make_ref_records(c, s, !c->accel_built_here, rc);
+    c->vox_of = nullptr;
+    if (r) return r;
+    HIP_TRY(c, hipEventRecord(c->ev[8], s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    c->accel_pending = false;
+    c->tm.build_expand_ms = ms_between(c->ev[5], c->ev[8]);
+    return HVRT_OK;
 }
 
 }  // namespace
@@ -384,13 +425,16 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipHostGetDevicePointer((void**)&c->split_hint_dev, c->split_hint, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     for (auto& ev : c->ev)
         if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc((void**)&c->stats, 72 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);   // 8 words + 64 striped totals
+    if ((e = hipMalloc((void**)&c->stats, STATS_STATUS * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
+    c->stats_capacity = STATS_STATUS;
     if ((e = hipMalloc((void**)&c->tile_counter, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->cost_sum, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->cam_dev, sizeof(hvrt_camera_frame) * hvrt_ctx::CAM_SLOTS * hvrt_ctx::CAM_MAX)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&c->cam_host, sizeof(hvrt_camera_frame) * hvrt_ctx::CAM_SLOTS * hvrt_ctx::CAM_MAX, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     for (auto& ev : c->cam_ev)
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if (const char* v = getenv("HVRT_BUILD_REUSE")) c->reuse_arrays = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_BUILD_NARROW")) c->narrow_counters = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_ABORT_US")) {
@@ -418,7 +462,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->df_stream) (void)hipStreamSynchronize(c->df_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->block_sums, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
+    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->cnt16, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -466,6 +510,19 @@ int hvrt_set_mode(hvrt_ctx* c, int mode) {
     if (mode != c->mode) c->cost_valid = false;     // tile durations of the other mode say nothing about this one
     c->mode = mode;
     return HVRT_OK;
+}
+
+int hvrt_set_deferred_accel(hvrt_ctx* c, int on) {
+    if (!c) return HVRT_ERR_INVALID;
+    c->defer_accel = on != 0;
+    return HVRT_OK;
+}
+
+int hvrt_finish_accel(hvrt_ctx* c) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "finish_accel: no grid");
+    return finish_accel(c);
 }
 
 int hvrt_get_timings(const hvrt_ctx* c, hvrt_timings* out) {
@@ -557,73 +614,126 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     if (!c->tri_aos && c->n_tris) return fail(c, HVRT_ERR_INVALID, "build_grid: no mesh");
     c->has_grid = false;
     c->cost_valid = false;
+    c->accel_pending = false;
     (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
     set_grid_params(c, nx, ny, nz, mn, mx, vs);
     const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox), n_chunks = npad / SCAN_CHUNK;
 
     if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
     if (int r = ensure<uint32_t>(c, c->ranges, c->ranges_capacity, (uint64_t)c->n_tris * 3)) return r;
-    if (int r = ensure<uint64_t>(c, c->block_sums, c->block_sums_capacity, 2 * n_chunks)) return r;
     if (int r = ensure<uint32_t>(c, c->occ_bits, c->occ_bits_capacity, npad / 32)) return r;
+    if (c->stats_capacity < STATS_STATUS + 2 * n_chunks) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));            // a render may still be reading nothing of it, but be sure
+        if (int r = ensure<uint64_t>(c, c->stats, c->stats_capacity, STATS_STATUS + 2 * n_chunks)) return r;
+    }
     c->occ_bits_valid = false;
 
     hipStream_t s = c->stream;
-    HIP_TRY(c, hipEventRecord(c->ev[0], s));
-    HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->stats, 0, 72 * sizeof(uint64_t), s));
-    HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, cnt_of(c), c->ranges, c->stats, s));
-    HIP_TRY(c, hipEventRecord(c->ev[1], s));
-    HIP_TRY(c, launch_scan(cnt_of(c), n_chunks, c->block_sums, c->stats, c->occ_bits, s));
-    c->occ_bits_valid = true;
-    // With the occupancy bitmap the distance field needs nothing else: it starts now, on its own stream, beside
-    // the fill (which waits on atomics, not on bandwidth).  Beside the list-ordering kernel -- where it ran before
-    // -- its streaming sweeps pushed that kernel's re-read lists out of L2 (3.1 ms for the two together at 1024^3,
-    // against 1.2 + 1.9 apart).  Grids whose x extent the bitmap kernel does not take are forked after the fill.
-    if (nx % 4 == 0 && nx <= 16384) if (int r = fork_distance_field(c, s)) return r;
-    HIP_TRY(c, hipEventRecord(c->ev[2], s));
-    uint64_t h_stats[72];
-    HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipStreamSynchronize(s));
-    h_stats[7] = 0;
-    for (int k = 8; k < 72; ++k) h_stats[7] += h_stats[k];      // the count pass's striped 64-bit total
-    if (h_stats[5]) return fail(c, HVRT_ERR_HIP, "build_grid: the offset scan gave up waiting for a chunk (device fault?)");
-    // h_stats[7]: the count pass's own 64-bit total -- the scan's total (h_stats[0]) comes out of 32-bit partial sums
-    // and is only meaningful once this one is known to fit; nothing has been scattered yet
-    if (h_stats[7] > 0xFFFFFFFFull)
-        return fail(c, HVRT_ERR_OVERFLOW, "build_grid: %llu triangle references exceed the u32 CSR", (unsigned long long)h_stats[7]);
-    const uint64_t total = h_stats[0];
-    if (total != h_stats[7])
-        return fail(c, HVRT_ERR_HIP, "build_grid: the scan's total (%llu) is not the count pass's (%llu)",
-                    (unsigned long long)total, (unsigned long long)h_stats[7]);
-    if (int r = ensure<uint32_t>(c, c->indices, c->indices_capacity, total)) return r;
-    if (int r = ensure<uint32_t>(c, c->long_queue, c->long_queue_capacity, total / 64 + 1)) return r;
-    if (int r = ensure<uint32_t>(c, c->fill_scratch, c->fill_scratch_capacity, 2 * total)) return r;
-    uint32_t* unsorted = c->fill_scratch;
-    uint32_t* vox_of = c->fill_scratch + total;
+    uint64_t* const status_aux = c->stats + STATS_STATUS;
+    // count + scan.  The counters are 16-bit while no list of this context has outgrown them: 2 bytes per voxel to
+    // clear and to read instead of 4, and the 32-bit offsets array is written once instead of cleared, counted into
+    // and scanned in place (1024^3: 8.6 GB of traffic instead of 12.9).  A counter that carried shows as a total
+    // that differs from the count pass's own (stats[0] != stats[7]); the front is then issued again with wide counters.
+    auto front = [&](bool narrow) -> int {
+        HIP_TRY(c, hipEventRecord(c->ev[0], s));
+        if (narrow) {
+            if (int r = ensure<uint32_t>(c, c->cnt16, c->cnt16_capacity, npad / 2)) return r;
+            HIP_TRY(c, hipMemsetAsync(c->cnt16, 0, npad / 2 * sizeof(uint32_t), s));
+            HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, 4 * sizeof(uint32_t), s));       // offsets[0]
+        } else {
+            HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
+        }
+        HIP_TRY(c, hipMemsetAsync(c->stats, 0, (STATS_STATUS + n_chunks) * sizeof(uint64_t), s));
+        HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, narrow ? c->cnt16 : cnt_of(c), narrow, c->stats + STATS_VOL_SUMS, c->ranges, s));
+        HIP_TRY(c, hipEventRecord(c->ev[1], s));
+        HIP_TRY(c, launch_scan(cnt_of(c), narrow ? c->cnt16 : nullptr, c->stats + STATS_VOL_SUMS, n_chunks, status_aux, c->stats, c->occ_bits, s));
+        c->occ_bits_valid = true;
+        // With the occupancy bitmap the distance field needs nothing else: it starts now, on its own stream, beside
+        // the fill (which waits on atomics, not on bandwidth).  Beside the list-ordering kernel -- where it ran before
+        // -- its streaming sweeps pushed that kernel's re-read lists out of L2 (3.1 ms for the two together at 1024^3,
+        // against 1.2 + 1.9 apart).  Grids whose x extent the bitmap kernel does not take are forked after the fill.
+        if (!c->defer_accel && nx % 4 == 0 && nx <= 16384) if (int r = fork_distance_field(c, s)) return r;
+        HIP_TRY(c, hipEventRecord(c->ev[2], s));
+        return HVRT_OK;
+    };
 
-    HIP_TRY(c, hipEventRecord(c->ev[3], s));
-    HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, s));
-    HIP_TRY(c, hipEventRecord(c->ev[4], s));
-    if (!c->dist_in_flight) if (int r = fork_distance_field(c, s)) return r;     // offsets are final from here on
-    HIP_TRY(c, launch_sort(offsets_of(c), unsorted, vox_of, total, c->indices, c->long_queue, c->long_queue_capacity, c->stats, s));
-    HIP_TRY(c, hipEventRecord(c->ev[5], s));
-    c->n_refs = total;
-    c->vox_of = vox_of;
-    const int rr = make_ref_records(c, s, false);
-    c->vox_of = nullptr;
-    if (rr) return rr;
-    HIP_TRY(c, hipEventRecord(c->ev[8], s));
-    HIP_TRY(c, hipStreamSynchronize(s));
+    uint64_t h_stats[8];
+    auto read_stats = [&]() -> int {
+        HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (h_stats[5]) return fail(c, HVRT_ERR_HIP, "build_grid: the offset scan gave up waiting for a chunk (device fault?)");
+        // stats[0] is exact in 64 bits; the offsets are 32-bit sums and only meaningful when it fits
+        if (h_stats[0] > 0xFFFFFFFFull)
+            return fail(c, HVRT_ERR_OVERFLOW, "build_grid: %llu triangle references exceed the u32 CSR", (unsigned long long)h_stats[0]);
+        return HVRT_OK;
+    };
+    // everything behind the scan: scatter, per-voxel order, derived data.  The scanned counters are untouched until the
+    // scatter really runs, so a tail that found its arrays too small can simply be issued again.
+    auto tail = [&](const RefCount& rc) -> int {
+        uint32_t* unsorted = c->fill_scratch;
+        uint32_t* vox_of = c->fill_scratch + rc.cap;
+        HIP_TRY(c, hipEventRecord(c->ev[3], s));
+        HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, rc, s));
+        HIP_TRY(c, hipEventRecord(c->ev[4], s));
+        if (!c->defer_accel && !c->dist_in_flight) if (int r = fork_distance_field(c, s)) return r;     // offsets are final from here on
+        HIP_TRY(c, launch_sort(offsets_of(c), unsorted, vox_of, rc, c->indices, c->long_queue, c->long_queue_capacity, c->stats, s));
+        HIP_TRY(c, hipEventRecord(c->ev[5], s));
+        c->vox_of = vox_of;
+        if (!c->defer_accel) if (int r = make_ref_records(c, s, false, rc)) return r;
+        HIP_TRY(c, hipEventRecord(c->ev[8], s));
+        return HVRT_OK;
+    };
+    auto size_arrays = [&](uint64_t total) -> int {
+        // an eighth more than needed: the next build of a scene that moved a little then fits and need not wait
+        const uint64_t want = total + total / 8;
+        const uint64_t cap = want > 0xFFFFFFFFull ? 0xFFFFFFFFull : want;
+        if (int r = ensure<uint32_t>(c, c->indices, c->indices_capacity, cap)) return r;
+        if (int r = ensure<uint32_t>(c, c->long_queue, c->long_queue_capacity, cap / 64 + 2)) return r;
+        if (int r = ensure<uint32_t>(c, c->fill_scratch, c->fill_scratch_capacity, 2 * cap)) return r;
+        return HVRT_OK;
+    };
+
+    // Arrays left by an earlier build: go on without the round trip to the host (the kernels read the count where the
+    // scan left it).  Otherwise wait for the count and size them.
+    uint64_t total = 0;
+    for (;;) {
+        const bool narrow = c->narrow_counters;
+        (void)join_distance_field(c, s);        // (second round only: the first one's field is being recomputed)
+        if (int r = front(narrow)) return r;
+        const uint64_t live_cap = c->reuse_arrays ? ref_capacity_of(c, !c->defer_accel) : 0;
+        bool went_ahead = live_cap > 0;
+        if (went_ahead) {
+            const RefCount rc = { c->stats, 0, live_cap };
+            if (int r = tail(rc)) return r;
+        }
+        if (int r = read_stats()) return r;
+        if (narrow && h_stats[0] != h_stats[7]) {      // a 16-bit counter carried: nothing was scattered, count again
+            c->narrow_counters = false;
+            continue;
+        }
+        total = h_stats[0];
+        if (went_ahead && total <= live_cap) break;
+        // no arrays yet, or too small (then nothing was scattered): size them and issue the tail (again)
+        if (int r = size_arrays(total)) return r;
+        const RefCount rc = { nullptr, total, c->fill_scratch_capacity / 2 };
+        if (int r = tail(rc)) return r;
+        HIP_TRY(c, hipStreamSynchronize(s));
+        break;
+    }
 
     c->n_refs = total;
+    c->face_words = face_words_for(total);
     c->n_occupied = h_stats[1];
     c->max_list = (uint32_t)h_stats[2];
     c->has_grid = true;
+    c->accel_pending = c->defer_accel;
+    c->accel_built_here = true;
+    if (!c->accel_pending) c->vox_of = nullptr;
     c->tm.build_count_ms = ms_between(c->ev[0], c->ev[1]);
     c->tm.build_scan_ms = ms_between(c->ev[1], c->ev[2]);
     c->tm.build_fill_ms = ms_between(c->ev[3], c->ev[4]);
     c->tm.build_sort_ms = ms_between(c->ev[4], c->ev[5]);
-    c->tm.build_expand_ms = ms_between(c->ev[5], c->ev[8]);
+    c->tm.build_expand_ms = c->accel_pending ? 0.0f : ms_between(c->ev[5], c->ev[8]);
     c->tm.build_total_ms = ms_between(c->ev[0], c->ev[8]);
     return HVRT_OK;
 }
@@ -635,6 +745,7 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
     if (!offsets || (n_refs && !indices)) return fail(c, HVRT_ERR_INVALID, "set_grid_csr: null array");
     if (n_refs > 0xFFFFFFFFull) return fail(c, HVRT_ERR_OVERFLOW, "set_grid_csr: too many references");
     c->has_grid = false;
+    c->accel_pending = false;
     c->occ_bits_valid = false;      // the bitmap belongs to the offsets of the last build
     c->cost_valid = false;
     (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
@@ -658,9 +769,16 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
         return fail(c, HVRT_ERR_INVALID, "grid: %llu CSR entries reference a triangle index >= %u",
                     (unsigned long long)h_stats[4], c->n_tris);
     c->n_refs = n_refs;
+    c->face_words = face_words_for(n_refs);
     c->n_occupied = h_stats[1];
     c->max_list = (uint32_t)h_stats[2];
-    if (int r = make_ref_records(c, s, true)) return r;
+    c->accel_pending = c->defer_accel;
+    c->accel_built_here = false;
+    c->vox_of = nullptr;
+    if (!c->defer_accel) {
+        const RefCount rc = { nullptr, n_refs, n_refs };
+        if (int r = make_ref_records(c, s, true, rc)) return r;
+    }
     c->has_grid = true;
     return HVRT_OK;
 }
@@ -710,6 +828,7 @@ int hvrt_get_distance_field(hvrt_ctx* c, uint8_t* dist) {
     if (int r = bind(c)) return r;
     if (!c->has_grid) return fail(c, HVRT_ERR_INVALID, "get_distance_field: no grid");
     if (!dist) return fail(c, HVRT_ERR_INVALID, "get_distance_field: null output");
+    if (int r = finish_accel(c)) return r;
     if (int r = download(c, dist, c->dist, c->g.nvox, c->stream)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HVRT_OK;
@@ -932,7 +1051,7 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
                                     void* d_t, void* d_counters) {
     if (!c) return HVRT_ERR_INVALID;
     if (int r = bind(c)) return r;
-    if (int r = require_scene(c)) return r;
+    if (int r = require_scene(c, false)) return r;
     if (!frame) return fail(c, HVRT_ERR_INVALID, "render: null camera frame");
     if (width < 1 || height < 1 || (uint64_t)width * height > 0x7FFFFFFFull)
         return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);

@@ -4,11 +4,12 @@
 // inline variants (SceneCreator.cu:67-358, InlineVoxelizer.h:17-167) with:
 //   k_count       one lane per triangle: AABB -> inclusive voxel range (SceneCreator.cpp:23-37,
 //                 177-188, GeometryUtils.cpp:43-51), atomic count per voxel with run-aggregated
-//                 atomics; big ranges are spread over the whole wave; the exact 64-bit number of
-//                 references goes to stats[8..71] (overflow check before anything is scattered)
+//                 atomics; big ranges are spread over the whole wave
 //   k_scan        exclusive scan of the counts in flat order ix + nx*(iy + ny*iz) in ONE pass over
 //                 the array (chained scan with decoupled look-back, 32768 counters per workgroup);
-//                 also leaves the one-bit-per-voxel occupancy map for the distance field
+//                 also leaves the one-bit-per-voxel occupancy map for the distance field and the exact
+//                 64-bit number of references in stats[0] (the offsets themselves are 32-bit: the host,
+//                 or the kernels behind the scan, refuse to scatter when that number does not fit)
 //   k_fill        scatter of triangle ids through atomic cursors (the scanned counts themselves:
 //                 after the fill cnt[v] == start(v+1), i.e. the buffer IS the CSR offsets array
 //                 shifted by one, so no separate cursor array and no copy)
@@ -43,6 +44,17 @@ __device__ __forceinline__ uint64_t flat_index(const GridParams& g, int ix, int 
     return (uint64_t)ix + (uint64_t)g.nx * ((uint64_t)iy + (uint64_t)g.ny * (uint64_t)iz);
 }
 
+// The number of CSR entries as the kernels behind the scan learn it (RefCount, hvrt_internal.hpp): either the host
+// read it back and sized the arrays (live == nullptr), or the build goes on without that round trip and every kernel
+// reads the scan's 64-bit total itself -- and does nothing when the arrays it would write (sized by an earlier
+// build) are too small; the host sees the same number at the end of the build and repeats the tail with new arrays.
+__device__ __forceinline__ bool ref_count(const RefCount& r, uint64_t& n) {
+    n = r.live ? r.live[0] : r.n;
+    // live[7]: the count pass's independent total (k_scan_stats); differs when a 16-bit counter carried
+    return n <= r.cap && (!r.live || r.live[7] == n);
+}
+__device__ __forceinline__ uint64_t face_words_of(uint64_t n_refs) { return (n_refs + 63) / 64 * 2 + 2; }
+
 // ------------------------------------------------------------------------------------------
 // records: v0, e1, e2, normal
 // ------------------------------------------------------------------------------------------
@@ -64,14 +76,24 @@ __global__ __launch_bounds__(256) void k_prepare_records(const float4* __restric
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t SMALL_VOL = 32;  // ranges up to this many voxels are walked by the owning lane
 
-template <bool FILL>
+// what a visit to a voxel does: count into 32-bit counters, count into 16-bit counters (two per word; a list of
+// 65536 or more entries carries into its neighbour -- the build notices, see k_scan_stats, and counts again in 32
+// bits), or take the next slot of the voxel's list (the cursors are the scanned counters, always 32-bit)
+enum { COUNT32 = 0, FILL = 1, COUNT16 = 2 };
+
+template <int MODE>
+__device__ __forceinline__ uint32_t bump(uint32_t* cnt, uint64_t f, uint32_t by) {
+    if (MODE == COUNT16) { atomicAdd(&cnt[f >> 1], by << (16u * (uint32_t)(f & 1ull))); return 0u; }
+    if (MODE == COUNT32) { atomicAdd(&cnt[f], by); return 0u; }
+    return atomicAdd(&cnt[f], by);
+}
+
+template <int MODE>
 __device__ __forceinline__ void touch(uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, uint64_t f, uint32_t t) {
-    if (FILL) {
-        uint32_t p = atomicAdd(&cnt[f], 1u);
+    const uint32_t p = bump<MODE>(cnt, f, 1u);
+    if (MODE == FILL) {
         indices[p] = t;
         vox_of[p] = (uint32_t)f;
-    } else {
-        atomicAdd(&cnt[f], 1u);
     }
 }
 
@@ -80,7 +102,7 @@ __device__ __forceinline__ void touch(uint32_t* cnt, uint32_t* indices, uint32_t
 // issues ONE atomicAdd of the run length (its first lane), and in the fill the others take consecutive
 // slots behind it.  A dense cluster of small triangles (thousands per voxel) otherwise serialises on a
 // handful of L2 atomic units.  Every lane of the wave must call this (ballot / shuffle inside).
-template <bool FILL>
+template <int MODE>
 __device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, bool act, uint32_t f, uint32_t t) {
     const int lane = threadIdx.x & 63;
     const unsigned long long S = __ballot(act);
@@ -95,9 +117,9 @@ __device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uin
     if (act && hl == lane) {
         const unsigned long long stop = (H | ~S) & ~(~0ull >> (63 - lane));   // next head or inactive lane above me
         const uint32_t len = (uint32_t)((stop ? __builtin_ctzll(stop) : 64) - lane);
-        base = atomicAdd(&cnt[f], len);
+        base = bump<MODE>(cnt, f, len);
     }
-    if (FILL) {
+    if (MODE == FILL) {
         base = __shfl(base, hl);
         if (act) {
             const uint32_t p = base + (uint32_t)(lane - hl);
@@ -107,7 +129,7 @@ __device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uin
     }
 }
 
-template <bool FILL>
+template <int MODE>
 __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, uint32_t t,
                                            bool valid, int lx, int ly, int lz, int hx, int hy, int hz) {
     const uint32_t dx = valid ? (uint32_t)(hx - lx + 1) : 0u;
@@ -122,7 +144,7 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
         int ix = lx, iy = ly, iz = lz;
         bool act = small;
         while (__ballot(act)) {
-            touch_runs<FILL>(cnt, indices, vox_of, act, (uint32_t)flat_index(g, ix, iy, iz), t);
+            touch_runs<MODE>(cnt, indices, vox_of, act, (uint32_t)flat_index(g, ix, iy, iz), t);
             if (act) {
                 if (++ix > hx) { ix = lx; if (++iy > hy) { iy = ly; if (++iz > hz) act = false; } }
             }
@@ -143,16 +165,20 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
             const uint32_t iz = (uint32_t)(i / plane);
             const uint32_t r = (uint32_t)(i - (uint64_t)iz * plane);
             const uint32_t iy = r / bdx, ix = r - iy * bdx;
-            touch<FILL>(cnt, indices, vox_of, flat_index(g, blx + (int)ix, bly + (int)iy, blz + (int)iz), bt);
+            touch<MODE>(cnt, indices, vox_of, flat_index(g, blx + (int)ix, bly + (int)iy, blz + (int)iz), bt);
         }
     }
 }
 
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v);
 
+// vol_sums (COUNT16 only): 64 words a cache line apart; every workgroup adds the number of references its triangles
+// make (the sum of their range volumes, exact in 64 bits) to one of them -- the independent total that tells a
+// carried 16-bit counter from a sound one
+template <int MODE>
 __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, uint32_t T, GridParams g,
                                                uint32_t* __restrict__ cnt, uint32_t* __restrict__ ranges,
-                                               uint64_t* __restrict__ stats) {
+                                               uint64_t* __restrict__ vol_sums) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool valid = t < T;
     int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
@@ -174,18 +200,24 @@ __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, u
         ranges[3ull * t + 2] = (uint32_t)lz | ((uint32_t)hz << 16);
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
-    // the number of references, exactly, in 64 bits: the scan adds the per-voxel counters up in 32-bit partial sums,
-    // which more than 2^32 - 1 references would wrap before the host could see them.  Summed per wave into 64 striped
-    // words (stats[8 + blockIdx % 64]; the host adds them up): thousands of atomics on ONE word cost the count pass
-    // more than its own work on a million triangles
-    const uint64_t vol = wave_sum64(nonempty ? (uint64_t)(hx - lx + 1) * (uint64_t)(hy - ly + 1) * (uint64_t)(hz - lz + 1) : 0ull);
-    if ((threadIdx.x & 63u) == 0u && vol) atomicAdd((unsigned long long*)&stats[8 + (blockIdx.x & 63u)], (unsigned long long)vol);
-    walk_range<false>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
+    if (MODE == COUNT16) {
+        __shared__ uint64_t s_vol[4];
+        const uint64_t vol = wave_sum64(nonempty ? (uint64_t)(hx - lx + 1) * (uint64_t)(hy - ly + 1) * (uint64_t)(hz - lz + 1) : 0ull);
+        if ((threadIdx.x & 63u) == 0u) s_vol[threadIdx.x >> 6] = vol;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint64_t all = s_vol[0] + s_vol[1] + s_vol[2] + s_vol[3];
+            if (all) atomicAdd((unsigned long long*)&vol_sums[16u * (blockIdx.x & 63u)], (unsigned long long)all);
+        }
+    }
+    walk_range<MODE>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
 }
 
 __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ ranges, uint32_t T, GridParams g,
                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ indices,
-                                              uint32_t* __restrict__ vox_of) {
+                                              uint32_t* __restrict__ vox_of, RefCount rc) {
+    uint64_t n_refs;
+    if (!ref_count(rc, n_refs)) return;      // uniform: the arrays are too small for this build, nothing is scattered
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool valid = t < T;
     int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
@@ -196,7 +228,7 @@ __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ range
         lz = (int)(rz & 0xFFFFu); hz = (int)(rz >> 16);
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
-    walk_range<true>(g, cnt, indices, vox_of, t, nonempty, lx, ly, lz, hx, hy, hz);
+    walk_range<FILL>(g, cnt, indices, vox_of, t, nonempty, lx, ly, lz, hx, hy, hz);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -238,11 +270,15 @@ constexpr uint32_t ST_SPIN_LIMIT = 1u << 22;
 constexpr int SCAN_WAVES = SCAN_CHUNK / 2048;       // 16 waves of 2048 counters each
 // occ_bits (nullable): one bit per voxel, "has a list" -- the counters are in registers here anyway, and the
 // distance field's x pass then reads 1/32 of what the offsets would cost it.
-__global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cnt4, uint64_t* __restrict__ status,
+// NARROW: the counters come from the 16-bit array (four per 8-byte load) and the offsets go to cnt4, which nothing
+// has written before (out of place: no memset of the 32-bit array, and half the bytes to read).
+template <bool NARROW>
+__global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cnt4, const uint2* __restrict__ cnt16,
+                                                          uint64_t* __restrict__ status,
                                                           uint64_t* __restrict__ aux, uint64_t* __restrict__ stats,
                                                           uint32_t* __restrict__ occ_bits) {
     __shared__ uint32_t s_chunk, s_w[SCAN_WAVES], s_occ[SCAN_WAVES], s_mx[SCAN_WAVES];
-    __shared__ uint64_t s_base;
+    __shared__ uint64_t s_base, s_w64[SCAN_WAVES];
     if (threadIdx.x == 0) s_chunk = atomicAdd(reinterpret_cast<uint32_t*>(stats + 6), 1u);
     __syncthreads();
     const uint64_t c = s_chunk;
@@ -250,12 +286,23 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cn
     uint4* p = cnt4 + c * (SCAN_CHUNK / 4) + w * 512 + lane;
     uint4 v[8];
     uint32_t excl[8];
+    if (NARROW) {
+        const uint2* q = cnt16 + c * (SCAN_CHUNK / 4) + w * 512 + lane;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = p[k * 64];
+        for (int k = 0; k < 8; ++k) {
+            const uint2 h = q[k * 64];
+            v[k] = make_uint4(h.x & 0xFFFFu, h.x >> 16, h.y & 0xFFFFu, h.y >> 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[k * 64];
+    }
     uint32_t carry = 0, occ = 0, mx = 0;
+    uint64_t exact = 0;     // my counters added up in 64 bits: the 32-bit sums below wrap beyond 2^32 - 1 references
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t tot = v[k].x + v[k].y + v[k].z + v[k].w;
+        exact += (uint64_t)v[k].x + (uint64_t)v[k].y + (uint64_t)v[k].z + (uint64_t)v[k].w;
         const uint32_t inc = wave_inclusive_scan(tot);
         excl[k] = carry + inc - tot;
         carry += __shfl(inc, 63);
@@ -274,13 +321,15 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cn
     }
     occ = (uint32_t)wave_sum64(occ);
     mx = wave_max32(mx);
-    if (lane == 0) { s_w[w] = carry; s_occ[w] = occ; s_mx[w] = mx; }
+    exact = wave_sum64(exact);
+    if (lane == 0) { s_w[w] = carry; s_occ[w] = occ; s_mx[w] = mx; s_w64[w] = exact; }
     __syncthreads();
     if (w == 0) {
         // wave 0: the waves' totals -> their exclusive prefixes (left in s_w), chunk total, statistics
         const uint32_t wt = lane < SCAN_WAVES ? s_w[lane] : 0u;
         const uint32_t winc = wave_inclusive_scan(wt);
-        const uint64_t total = __shfl(winc, 63);
+        // the chunk's total as the chain carries it: exact (at most 32768 x 2^32 < 2^62, the width of a status value)
+        const uint64_t total = wave_sum64(lane < SCAN_WAVES ? s_w64[lane] : 0ull);      // valid in lane 0, the only reader
         const uint32_t tocc = (uint32_t)wave_sum64(lane < SCAN_WAVES ? s_occ[lane] : 0u);
         const uint32_t tmx = wave_max32(lane < SCAN_WAVES ? s_mx[lane] : 0u);
         if (lane < SCAN_WAVES) s_w[lane] = winc - wt;
@@ -334,7 +383,15 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cn
     }
 }
 // occupied voxels and longest list: reduction of the per-chunk pairs
-__global__ __launch_bounds__(256) void k_scan_stats(const uint64_t* __restrict__ aux, uint64_t n, uint64_t* __restrict__ stats) {
+// vol_sums (nullable): the count pass's own total, striped (k_count<COUNT16>) -> stats[7]; without it stats[7] is
+// the scan's total, i.e. "nothing to compare against, the counters were wide".  stats[0] != stats[7] at the end:
+// a 16-bit counter carried, nothing built from these offsets may be used.
+__global__ __launch_bounds__(256) void k_scan_stats(const uint64_t* __restrict__ aux, uint64_t n, uint64_t* __restrict__ stats,
+                                                    const uint64_t* __restrict__ vol_sums) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        uint64_t sum = wave_sum64(vol_sums ? vol_sums[16u * threadIdx.x] : 0ull);
+        if (threadIdx.x == 0) stats[7] = vol_sums ? sum : stats[0];
+    }
     uint64_t occ = 0; uint32_t mx = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256u) {
         const uint64_t a = aux[i];
@@ -358,32 +415,41 @@ constexpr uint32_t SORT_MID = 4096;      // static-LDS bitonic (16 KiB)
 constexpr uint32_t SORT_BIG = 32768;     // dynamic-LDS bitonic (128 KiB of the CU's 160 KiB)
 
 // One lane per CSR entry: the entry's final position inside its voxel's list is the number of entries
-// of that list with a smaller triangle id (ids are unique within a list).  Lanes of one voxel read the same
-// few cache lines, the work per lane is the list length, and the result is written out of place -- no
-// per-voxel pass over the (mostly empty) grid and no serial insertion loops.  Longer lists are copied
-// through unchanged and queued once (by their first entry) for the bitonic kernels.
+// of that list with a smaller triangle id (ids are unique within a list).  A list of at most SORT_SMALL entries
+// that contains entry j lies inside [j - SORT_SMALL + 1, j + SORT_SMALL - 1], so a workgroup first brings the ids of
+// its 256 entries and of SORT_SMALL - 1 neighbours either side into LDS -- one coalesced pass -- and every lane then
+// counts over its list there (lanes of one list read the same word: a broadcast).  Reading the lists from global
+// memory instead made the kernel a chain of L1 wave-loads, one per list entry and lane (1.5 ms at 1024^3 for 109 M
+// entries, against 0.4 ms of traffic).  The result is written out of place.  Longer lists are copied through
+// unchanged and queued once (by their first entry) for the bitonic kernels.
 __global__ __launch_bounds__(256) void k_rank_sort(const uint32_t* __restrict__ unsorted, const uint32_t* __restrict__ vox_of,
-                                                   const uint32_t* __restrict__ offsets, uint64_t n_refs,
+                                                   const uint32_t* __restrict__ offsets, RefCount rc,
                                                    uint32_t* __restrict__ sorted, uint32_t* __restrict__ queue,
                                                    uint64_t queue_cap, uint64_t* __restrict__ stats) {
-    const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    constexpr uint32_t HALO = SORT_SMALL - 1;
+    __shared__ uint32_t s_key[256 + 2 * HALO];
+    uint64_t n_refs;
+    if (!ref_count(rc, n_refs)) return;
+    const uint64_t j0 = (uint64_t)blockIdx.x * 256u;
+    if (j0 >= n_refs) return;                                  // uniform over the workgroup
+    const uint64_t w0 = j0 >= HALO ? j0 - HALO : 0;            // first entry of the window
+    const uint64_t w1 = j0 + 256u + HALO < n_refs ? j0 + 256u + HALO : n_refs;
+    for (uint64_t q = w0 + threadIdx.x; q < w1; q += 256u) s_key[q - w0] = unsorted[q];
+    __syncthreads();
+    const uint64_t j = j0 + threadIdx.x;
     if (j >= n_refs) return;
     const uint32_t v = vox_of[j];
     const uint32_t b0 = offsets[v], b1 = offsets[(uint64_t)v + 1];
-    const uint32_t key = unsorted[j];
+    const uint32_t key = s_key[j - w0];
     const uint32_t len = b1 - b0;
     if (len <= SORT_SMALL) {
-        uint32_t rank = 0;
-        // (eight independent loads in flight: the loop is a chain of L1 / L2 latencies otherwise)
-        uint32_t q = b0;
-        for (; q + 8 <= b1; q += 8) {
-            uint32_t w[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) w[k] = unsorted[q + k];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) rank += w[k] < key;
+        const uint32_t* __restrict__ list = s_key + (b0 - (uint32_t)w0);
+        uint32_t rank = 0, q = 0;
+        for (; q + 4 <= len; q += 4) {
+            const uint32_t a = list[q], b = list[q + 1], c = list[q + 2], d = list[q + 3];
+            rank += (a < key) + (b < key) + (c < key) + (d < key);
         }
-        for (; q < b1; ++q) rank += unsorted[q] < key;
+        for (; q < len; ++q) rank += list[q] < key;
         sorted[b0 + rank] = key;
     } else {
         sorted[j] = key;
@@ -452,9 +518,11 @@ __global__ __launch_bounds__(NT) void k_sort_long(const uint32_t* __restrict__ o
 }
 
 // per-reference traversal records (SceneDev::ref_rec); also validates ingested indices (stats[4] = #bad)
-__global__ __launch_bounds__(256) void k_expand_records(const uint32_t* __restrict__ indices, uint64_t n_refs,
+__global__ __launch_bounds__(256) void k_expand_records(const uint32_t* __restrict__ indices, RefCount rc,
                                                         const float4* __restrict__ tri_rec, uint32_t n_tris,
                                                         float4* __restrict__ ref_rec, uint64_t* __restrict__ stats) {
+    uint64_t n_refs;
+    if (!ref_count(rc, n_refs)) return;
     const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (j >= n_refs) return;
     const uint32_t ti = indices[j];
@@ -485,10 +553,13 @@ __device__ __forceinline__ bool list_contains(const uint32_t* __restrict__ indic
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_face_bits(const uint32_t* __restrict__ indices, uint64_t n_refs,
+__global__ __launch_bounds__(256) void k_face_bits(const uint32_t* __restrict__ indices, RefCount rc,
                                                    const uint32_t* __restrict__ offsets, GridParams g, uint32_t n_tris,
                                                    const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ vox_of,
-                                                   uint32_t* __restrict__ face_bits, uint64_t face_words) {
+                                                   uint32_t* __restrict__ face_bits) {
+    uint64_t n_refs;
+    if (!ref_count(rc, n_refs)) return;
+    const uint64_t face_words = face_words_of(n_refs);      // the stride between the six bit planes (SceneDev::face_words)
     const uint64_t j = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     uint32_t mask = 0;
     if (j < n_refs) {
@@ -929,31 +1000,33 @@ hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* ranges,
-                        uint64_t* stats, hipStream_t s) {
+hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, bool narrow, uint64_t* vol_sums,
+                        uint32_t* ranges, hipStream_t s) {
     if (T == 0) return hipSuccess;
-    k_count<<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, stats);
+    if (narrow) k_count<COUNT16><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, vol_sums);
+    else k_count<COUNT32><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, nullptr);
     return hipGetLastError();
 }
 
-hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, uint32_t* occ_bits, hipStream_t s) {
-    // status words must start empty; the ticket (stats[6]) and the failure flag (stats[5]) were zeroed with stats
-    hipError_t e = hipMemsetAsync(status_aux, 0, n_chunks * sizeof(uint64_t), s);
-    if (e != hipSuccess) return e;
-    k_scan<<<(unsigned)n_chunks, SCAN_WAVES * 64, 0, s>>>((uint4*)cnt, status_aux, status_aux + n_chunks, stats, occ_bits);
+hipError_t launch_scan(uint32_t* cnt, const uint32_t* cnt16, const uint64_t* vol_sums, uint64_t n_chunks, uint64_t* status_aux,
+                       uint64_t* stats, uint32_t* occ_bits, hipStream_t s) {
+    // status words must start empty (the caller zeroed them with the counters); the ticket (stats[6]) and the failure
+    // flag (stats[5]) were zeroed with stats
+    if (cnt16) k_scan<true><<<(unsigned)n_chunks, SCAN_WAVES * 64, 0, s>>>((uint4*)cnt, (const uint2*)cnt16, status_aux, status_aux + n_chunks, stats, occ_bits);
+    else k_scan<false><<<(unsigned)n_chunks, SCAN_WAVES * 64, 0, s>>>((uint4*)cnt, nullptr, status_aux, status_aux + n_chunks, stats, occ_bits);
     const uint64_t blocks = (n_chunks + 2047) / 2048;
-    k_scan_stats<<<(unsigned)(blocks > 256 ? 256 : blocks), 256, 0, s>>>(status_aux + n_chunks, n_chunks, stats);
+    k_scan_stats<<<(unsigned)(blocks > 256 ? 256 : blocks), 256, 0, s>>>(status_aux + n_chunks, n_chunks, stats, cnt16 ? vol_sums : nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_fill(const uint32_t* ranges, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* indices,
-                       uint32_t* vox_of, hipStream_t s) {
+                       uint32_t* vox_of, const RefCount& rc, hipStream_t s) {
     if (T == 0) return hipSuccess;
-    k_fill<<<(T + 255) / 256, 256, 0, s>>>(ranges, T, g, cnt, indices, vox_of);
+    k_fill<<<(T + 255) / 256, 256, 0, s>>>(ranges, T, g, cnt, indices, vox_of, rc);
     return hipGetLastError();
 }
 
-hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, uint64_t n_refs,
+hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, const RefCount& rc,
                        uint32_t* indices, uint32_t* queue, uint64_t queue_cap, uint64_t* stats, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
@@ -962,28 +1035,30 @@ hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    if (n_refs == 0) return hipSuccess;
-    k_rank_sort<<<(unsigned)((n_refs + 255) / 256), 256, 0, s>>>(unsorted, vox_of, offsets, n_refs, indices, queue, queue_cap, stats);
+    const uint64_t n_launch = rc.live ? rc.cap : rc.n;       // lanes to launch: the capacity when the number is still on the device
+    if (n_launch == 0) return hipSuccess;
+    k_rank_sort<<<(unsigned)((n_launch + 255) / 256), 256, 0, s>>>(unsorted, vox_of, offsets, rc, indices, queue, queue_cap, stats);
     k_sort_long<0, 256><<<2048, 256, 0, s>>>(offsets, indices, queue, queue_cap, stats);
     k_sort_long<1, 1024><<<256, 1024, SORT_BIG * sizeof(uint32_t), s>>>(offsets, indices, queue, queue_cap, stats);
     k_sort_long<2, 1024><<<256, 1024, 0, s>>>(offsets, indices, queue, queue_cap, stats);
     return hipGetLastError();
 }
 
-hipError_t launch_expand_records(const uint32_t* indices, uint64_t n_refs, const float4* tri_rec, uint32_t n_tris,
+hipError_t launch_expand_records(const uint32_t* indices, const RefCount& rc, const float4* tri_rec, uint32_t n_tris,
                                  float4* ref_rec, uint64_t* stats, hipStream_t s) {
-    if (n_refs == 0) return hipSuccess;
-    k_expand_records<<<(unsigned)((n_refs + 255) / 256), 256, 0, s>>>(indices, n_refs, tri_rec, n_tris, ref_rec, stats);
+    const uint64_t n_launch = rc.live ? rc.cap : rc.n;
+    if (n_launch == 0) return hipSuccess;
+    k_expand_records<<<(unsigned)((n_launch + 255) / 256), 256, 0, s>>>(indices, rc, tri_rec, n_tris, ref_rec, stats);
     return hipGetLastError();
 }
 
-hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint32_t* offsets, const GridParams& g,
-                            uint32_t n_tris, const uint32_t* ranges, const uint32_t* vox_of, uint32_t* face_bits,
-                            uint64_t face_words, hipStream_t s) {
+uint64_t face_words_for(uint64_t n_refs) { return (n_refs + 63) / 64 * 2 + 2; }
+
+hipError_t launch_face_bits(const uint32_t* indices, const RefCount& rc, const uint32_t* offsets, const GridParams& g,
+                            uint32_t n_tris, const uint32_t* ranges, const uint32_t* vox_of, uint32_t* face_bits, hipStream_t s) {
     // one lane per entry, rounded up so that every 64-bit word of the arrays (incl. the tail) is written
-    const uint64_t lanes = (face_words * 32 + 255) / 256 * 256;
-    if (lanes == 0) return hipSuccess;
-    k_face_bits<<<(unsigned)(lanes / 256), 256, 0, s>>>(indices, n_refs, offsets, g, n_tris, ranges, vox_of, face_bits, face_words);
+    const uint64_t lanes = (face_words_for(rc.live ? rc.cap : rc.n) * 32 + 255) / 256 * 256;
+    k_face_bits<<<(unsigned)(lanes / 256), 256, 0, s>>>(indices, rc, offsets, g, n_tris, ranges, vox_of, face_bits);
     return hipGetLastError();
 }
 

@@ -91,25 +91,45 @@ struct RenderArgs {
 constexpr int SCAN_CHUNK = 32768;  // counters per scan workgroup (1024 threads x 32)
 
 hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t n_tris, hipStream_t s);
-// stats[8 .. 71] += the exact number of references, striped over 64 words (64-bit; zero on entry)
-hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
-                        uint32_t* ranges, uint64_t* stats, hipStream_t s);
-// in-place exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64 of scratch.
-// stats[0] <- total, stats[1] += occupied voxels, stats[2] <- longest list, stats[5] != 0: the scan gave up
-// (stats[5], stats[6] must be zero on entry)
+// Build statistics block (one allocation, zeroed with one memset per build):
+//   [0, 8)              stats: 0 total references (exact, 64-bit), 1 occupied voxels, 2 longest list, 3 long-list queue
+//                       length, 4 bad indices, 5 "the scan gave up", 6 scan ticket, 7 the count pass's own total
+//   [8, 8 + 1024)       vol_sums: 64 words a cache line apart (k_count with 16-bit counters)
+//   [1032, 1032 + n)    scan status words, then n aux words (n = chunks of the scan)
+constexpr uint64_t STATS_VOL_SUMS = 8, STATS_STATUS = 8 + 1024;
+// narrow: cnt is the 16-bit counter array (two per word; zero on entry) and vol_sums collects the exact total
+hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt, bool narrow,
+                        uint64_t* vol_sums, uint32_t* ranges, hipStream_t s);
+// exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64, the first n_chunks zero on entry.
+// cnt16 == nullptr: in place over cnt.  Otherwise the counters are read from cnt16 and the offsets written to cnt.
+// stats[0] <- total (exact, 64-bit, whatever the 32-bit offsets did), stats[1] += occupied voxels, stats[2] <- longest
+// list, stats[5] != 0: the scan gave up (stats[5], stats[6] must be zero on entry), stats[7] <- sum of vol_sums
+// (narrow) or stats[0]
 // occ_bits (nullable): n_chunks x SCAN_CHUNK / 32 words, one bit per voxel "has a list"
-hipError_t launch_scan(uint32_t* cnt, uint64_t n_chunks, uint64_t* status_aux, uint64_t* stats, uint32_t* occ_bits, hipStream_t s);
+hipError_t launch_scan(uint32_t* cnt, const uint32_t* cnt16, const uint64_t* vol_sums, uint64_t n_chunks, uint64_t* status_aux,
+                       uint64_t* stats, uint32_t* occ_bits, hipStream_t s);
+
+// How the kernels behind the scan learn the number of CSR entries.  live == nullptr: the host knows it (n), the arrays
+// hold at least that many.  live != nullptr: it is read on the device (live = the stats block: [0] the scan's total,
+// [7] the count pass's own); the arrays hold cap entries, launches are sized for cap, and a build that needs more --
+// or whose two totals differ -- writes nothing (the host notices at the end).
+struct RefCount {
+    const uint64_t* live;
+    uint64_t n;
+    uint64_t cap;
+};
+uint64_t face_words_for(uint64_t n_refs);    // words per bit plane of face_bits (SceneDev::face_words)
 hipError_t launch_fill(const uint32_t* ranges, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
-                       uint32_t* indices_unsorted, uint32_t* vox_of, hipStream_t s);
-hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, uint64_t n_refs,
+                       uint32_t* indices_unsorted, uint32_t* vox_of, const RefCount& rc, hipStream_t s);
+hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, const RefCount& rc,
                        uint32_t* indices, uint32_t* long_queue, uint64_t long_queue_capacity, uint64_t* stats,
                        hipStream_t s);
-hipError_t launch_expand_records(const uint32_t* indices, uint64_t n_refs, const float4* tri_rec, uint32_t n_tris,
+hipError_t launch_expand_records(const uint32_t* indices, const RefCount& rc, const float4* tri_rec, uint32_t n_tris,
                                  float4* ref_rec, uint64_t* stats, hipStream_t s);
-hipError_t launch_face_bits(const uint32_t* indices, uint64_t n_refs, const uint32_t* offsets, const GridParams& g,
+hipError_t launch_face_bits(const uint32_t* indices, const RefCount& rc, const uint32_t* offsets, const GridParams& g,
                             uint32_t n_tris, const uint32_t* ranges /* null: search the neighbour lists */,
                             const uint32_t* vox_of /* null: search the offsets */,
-                            uint32_t* face_bits, uint64_t face_words, hipStream_t s);
+                            uint32_t* face_bits /* 6 x face_words_for(entries) */, hipStream_t s);
 // occ_bits: the bitmap launch_scan left for THESE offsets, or null (occupancy is then read from the offsets)
 hipError_t launch_distance_field(const uint32_t* offsets, const uint32_t* occ_bits, const GridParams& g, uint8_t* dist, hipStream_t s);
 // stats[1] += occupied voxels, stats[2] <- longest list, stats[6] += offsets that break the CSR rules (offsets[0] == 0,

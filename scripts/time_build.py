@@ -16,12 +16,19 @@ elif which == "c2":
     tris, g = meshgen.cube_sphere(289), 256
 print(f"{which}: mesh {tris.shape[0]} triangles generated in {time.time()-t0:.1f}s", flush=True)
 ctx = ra.Context(0)
+defer = len(sys.argv) > 2 and sys.argv[2] == "defer"
+ctx.set_deferred_accel(defer)
 t0 = time.time(); ctx.set_mesh(tris); print(f"upload {time.time()-t0:.2f}s", flush=True)
 mn, mx = ctx.mesh_bounds()
 vs = capi.voxel_size(mn, mx, g, g, g)
 for rep in range(4):
     info = ctx.build_grid(g, g, g, mn, mx, vs)
     tm = ctx.timings()
+    if defer:
+        csr_total = tm.build_total_ms
+        ctx.finish_accel()
+        tm2 = ctx.timings()
+        print(f"  deferred: CSR alone {csr_total:.3f} ms, derived data afterwards {tm2.build_expand_ms:.3f} ms")
     nv = g ** 3
     b = 72.0 * info.n_triangles + 12.0 * nv + 20.0 * info.n_refs
     print(f"  build total {tm.build_total_ms:.3f} ms (count {tm.build_count_ms:.3f} scan {tm.build_scan_ms:.3f} fill {tm.build_fill_ms:.3f} "

@@ -252,3 +252,75 @@ def test_config5_full_size_csr(ctx):
     want = np.where(m == 255, 255, m + 1).astype(np.uint8)
     free = d != 0
     assert np.array_equal(d[free], want[free])
+
+
+def _fresh(env=None):
+    import os
+    import raytracer_amd as ra
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        return ra.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("reuse", ["1", "0"])
+def test_builds_that_go_on_without_the_host_match_sized_builds(reuse):
+    """A context that has built before keeps its arrays and lets the kernels behind the scan read the reference count
+    on the device (no host round trip); a build that outgrows the arrays writes nothing and is repeated with new ones.
+    Small -> large (outgrows) -> small (fits) -> the same again, every CSR against the oracle, every frame against a
+    context that always waits for the count (HVRT_BUILD_REUSE=0 runs the same sequence that way)."""
+    c = _fresh({"HVRT_BUILD_REUSE": reuse})
+    try:
+        scenes = [(meshgen.cube_sphere(10), (16, 16, 16)), (meshgen.skewed_statue(30, 200), (48, 48, 48)),
+                  (meshgen.cube_sphere(14), (20, 20, 20)), (meshgen.cube_sphere(14), (20, 20, 20)),
+                  (meshgen.random_soup(3000, 4), (31, 9, 40))]
+        for tris, dims in scenes:
+            info, off, idx, mn, mx, vs = build_both(c, tris, dims)
+            fr = capi.make_camera_frame(*capi.default_camera(mn, mx, "front"))
+            rgb, hit, t, cnt = c.render(fr, 160, 120)
+            orgb, ohit, ot, ocnt = oracle.OracleScene(tris, *dims, mn, vs, off, idx).render(fr, 160, 120)
+            assert np.array_equal(hit, ohit) and np.array_equal(rgb.view(np.uint32), orgb.view(np.uint32))
+            assert np.array_equal(cnt, ocnt)
+    finally:
+        c.close()
+
+
+def test_deferred_acceleration_data(ctx):
+    """hvrt_set_deferred_accel: the build returns after the CSR; distance field, face bits and records appear at first use
+    and the frames are the ones an eager build gives."""
+    tris, dims = meshgen.skewed_statue(24, 80), (40, 40, 40)
+    c = _fresh()
+    try:
+        c.set_deferred_accel(True)
+        for _ in range(2):                         # the second build reuses the first one's arrays
+            info, off, idx, mn, mx, vs = build_both(c, tris, dims)      # ends with get_distance_field: builds the data
+            assert c.timings().build_expand_ms > 0.0
+        c.build_grid(*dims, mn, mx, vs)
+        assert c.timings().build_expand_ms == 0.0
+        fr = capi.make_camera_frame(*capi.default_camera(mn, mx, "front"))
+        import torch
+        d = torch.empty((64, 64, 3), dtype=torch.float32, device="cuda:0")
+        with pytest.raises(capi.HvrtError, match="hvrt_finish_accel"):
+            c.render_part_device_noalloc(fr, 64, 64, 1, 0, 16, 0, 1, d.data_ptr())
+        rgb, hit, t, cnt = c.render(fr, 200, 150)               # first use builds the derived data
+        assert c.timings().build_expand_ms > 0.0
+        ctx.set_mesh(tris)
+        ctx.build_grid(*dims, mn, mx, vs)
+        rgb2, hit2, t2, cnt2 = ctx.render(fr, 200, 150)
+        assert np.array_equal(hit, hit2) and np.array_equal(rgb.view(np.uint32), rgb2.view(np.uint32))
+        assert np.array_equal(t.view(np.uint32), t2.view(np.uint32)) and np.array_equal(cnt, cnt2)
+        # an ingested CSR, deferred, then finished explicitly
+        c.set_grid_csr(*dims, mn, mx, vs, off, idx)
+        c.finish_accel()
+        rgb3, hit3, *_ = c.render(fr, 200, 150)
+        assert np.array_equal(hit, hit3) and np.array_equal(rgb.view(np.uint32), rgb3.view(np.uint32))
+    finally:
+        c.close()
