@@ -287,6 +287,33 @@ int hvrt_trace(hvrt_ctx* ctx, const float* origins, const float* dirs, uint32_t 
 int hvrt_trace_device(hvrt_ctx* ctx, const void* d_origins, const void* d_dirs, uint32_t n,
                       void* d_hits, void* d_counters);
 
+/* Device -> the caller's (pageable) host memory through the context's ring of pinned chunks (what hvrt_render uses for
+ * its frames: a plain DMA into pageable memory runs at a third of the link).  Synchronous.  No reference counterpart. */
+int hvrt_download(hvrt_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+
+/* ---- several GPUs of one node ---------------------------------------------------------------
+ * No counterpart in the reference (one thread on one CPU); the seam a maintainer would use is the tracer factory,
+ * TraceImages.cpp:464-484.  One process, one context per device: the scene is replicated, a frame's 16-row tiles
+ * are interleaved over the members (tile k -> member k % n), the slabs travel to member 0 -- RCCL (ncclCommInitAll,
+ * ncclBroadcast of the scene, grouped ncclSend / ncclRecv of the slabs; librccl is opened at run time) or, with
+ * HVRT_GROUP_TRANSPORT=copy or when a device is listed twice, device-to-device copies -- and member 0 reassembles
+ * the frame.  Results are bit for bit those of one context.  A group of one device needs no transport at all. */
+typedef struct hvrt_group hvrt_group;
+int hvrt_device_count(void);                                  /* visible HIP devices (0 when there is none) */
+int hvrt_group_create(hvrt_group** out, const int* device_ids, int n_devices);
+void hvrt_group_destroy(hvrt_group* group);
+const char* hvrt_group_last_error(const hvrt_group* group);   /* group == NULL: why hvrt_group_create failed (this thread) */
+int hvrt_group_size(const hvrt_group* group);
+const char* hvrt_group_transport(const hvrt_group* group);    /* "rccl", "copy" or "none" (one member) */
+/* Member i's context (owned by the group).  Member 0 is where the caller sets the mesh and builds or ingests the grid. */
+hvrt_ctx* hvrt_group_member(hvrt_group* group, int i);
+/* Member 0's mesh and CSR to every other member (each derives its own acceleration data).  Synchronous. */
+int hvrt_group_replicate_scene(hvrt_group* group);
+/* hvrt_render over the group: rgb W*H*3 floats (host), counters / hits nullable (summed over the members;
+ * hits = pixels whose sample-0 ray hit a triangle, as hvrt_last_hit_count).  Synchronous. */
+int hvrt_group_render(hvrt_group* group, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,
+                      float* rgb, uint64_t counters[2], uint64_t* hits);
+
 #ifdef __cplusplus
 }
 #endif

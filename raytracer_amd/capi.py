@@ -25,7 +25,9 @@ SYMBOLS = [
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc", "hvrt_last_hit_count",
-    "hvrt_set_deferred_accel", "hvrt_finish_accel",
+    "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count",
+    "hvrt_group_create", "hvrt_group_destroy", "hvrt_group_last_error", "hvrt_group_size", "hvrt_group_transport",
+    "hvrt_group_member", "hvrt_group_replicate_scene", "hvrt_group_render",
 ]
 
 
@@ -109,6 +111,19 @@ def load_library() -> C.CDLL:
                                             C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.hvrt_render_part_device_noalloc.argtypes = lib.hvrt_render_part_device.argtypes
     lib.hvrt_last_hit_count.argtypes = [vp, C.POINTER(C.c_uint64)]
+    lib.hvrt_download.argtypes = [vp, vp, vp, C.c_uint64]
+    lib.hvrt_group_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    lib.hvrt_group_destroy.argtypes = [vp]
+    lib.hvrt_group_destroy.restype = None
+    lib.hvrt_group_last_error.argtypes = [vp]
+    lib.hvrt_group_last_error.restype = C.c_char_p
+    lib.hvrt_group_size.argtypes = [vp]
+    lib.hvrt_group_transport.argtypes = [vp]
+    lib.hvrt_group_transport.restype = C.c_char_p
+    lib.hvrt_group_member.argtypes = [vp, C.c_int]
+    lib.hvrt_group_member.restype = vp
+    lib.hvrt_group_replicate_scene.argtypes = [vp]
+    lib.hvrt_group_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp]
     lib.hvrt_set_deferred_accel.argtypes = [vp, C.c_int]
     lib.hvrt_finish_accel.argtypes = [vp]
     lib.hvrt_render_batch_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
@@ -173,6 +188,57 @@ def default_camera(min_bound, max_bound, view: str = "front", aspect: float = 80
 
 
 @dataclass
+class Group:
+    """Several GPUs of one node (include/hvrt.h, group section): member 0 holds the scene the caller sets, replicate()
+    hands it to the others, render() traces a frame over all of them."""
+
+    def __init__(self, device_ids):
+        self._lib = load_library()
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        h = C.c_void_p()
+        rc = self._lib.hvrt_group_create(C.byref(h), ids, len(device_ids))
+        if rc != 0:
+            raise HvrtError(rc, self._lib.hvrt_group_last_error(None).decode())
+        self._g = h
+        self.root = Context.__new__(Context)           # member 0, owned by the group
+        self.root._lib, self.root._h, self.root._borrowed = self._lib, C.c_void_p(self._lib.hvrt_group_member(h, 0)), True
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise HvrtError(rc, self._lib.hvrt_group_last_error(self._g).decode())
+
+    @property
+    def size(self) -> int:
+        return self._lib.hvrt_group_size(self._g)
+
+    @property
+    def transport(self) -> str:
+        return self._lib.hvrt_group_transport(self._g).decode()
+
+    def replicate(self):
+        self._ck(self._lib.hvrt_group_replicate_scene(self._g))
+
+    def render(self, frame: CameraFrame, width: int, height: int, spp: int = 1, seed: int = 0):
+        rgb = np.empty((height, width, 3), np.float32)
+        cnt = np.zeros(2, np.uint64)
+        hits = C.c_uint64()
+        self._ck(self._lib.hvrt_group_render(self._g, C.byref(frame), width, height, spp, seed, _ptr(rgb), _ptr(cnt),
+                                             C.cast(C.byref(hits), C.c_void_p)))
+        return rgb, cnt, int(hits.value)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self.root._h = None
+            self._lib.hvrt_group_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BuildResult:
     info: GridInfo
     timings: Timings
@@ -190,7 +256,7 @@ class Context:
         self._h = h
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and not getattr(self, "_borrowed", False):
             self._lib.hvrt_destroy(self._h)
             self._h = None
 

@@ -1046,6 +1046,20 @@ int hvrt_render_part_device(hvrt_ctx* c, const hvrt_camera_frame* frame, int wid
                                          d_rgb, d_hit_id, d_t, d_counters);
 }
 
+int hvrt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int hvrt_download(hvrt_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (bytes && (!dst || !d_src)) return fail(c, HVRT_ERR_INVALID, "download: null pointer");
+    if (int r = download(c, dst, d_src, bytes, c->stream)) return r;
+    return hvrt_synchronize(c);
+}
+
 int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp,
                                     uint32_t seed, int tile_rows, int part, int n_parts, void* d_rgb, void* d_hit_id,
                                     void* d_t, void* d_counters) {
@@ -1244,3 +1258,13 @@ int hvrt_trace_device(hvrt_ctx* c, const void* d_origins, const void* d_dirs, ui
 }
 
 }  // extern "C"
+
+// for hvrt_group.hip: hvrt_render_part_device that also counts the pixels whose (sample-0) ray hit a triangle
+namespace hvrt {
+int render_part_counting_hits(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,
+                              int tile_rows, int part, int n_parts, void* d_rgb, void* d_counters, void* d_hits) {
+    const int rows = hvrt_part_rows(height, tile_rows, part, n_parts);
+    return render_batch_part(c, frame, 1, width, height, spp, seed, tile_rows, part, n_parts, rows, d_rgb, nullptr, nullptr,
+                             d_counters, d_hits);
+}
+}  // namespace hvrt

@@ -1,6 +1,7 @@
 // HipVoxelRayTracer.cpp -- see the header.  Plain C++17, links libhvrt; no HIP headers.
 #include "HipVoxelRayTracer.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -32,10 +33,53 @@ inline void ck(hvrt_ctx* c, int rc, const char* what) {
 // ------------------------------------------------------------------------------------------ HipScene
 
 HipScene::HipScene(int device_id) {
-    if (hvrt_create(&ctx_, device_id) != HVRT_OK) raise(nullptr, "hvrt_create");
+    // which devices: HVRT_DEVICES ("0,1,2", "all"), else device_id alone -- a group is only formed when asked for or
+    // when listing several; a device may be listed twice (two contexts on one GPU, the copy transport)
+    std::vector<int> ids;
+    if (const char* e = std::getenv("HVRT_DEVICES")) {
+        const std::string v(e);
+        if (v == "all") {
+            const int n = hvrt_device_count();
+            for (int i = 0; i < n; ++i) ids.push_back(i);
+        } else {
+            size_t p = 0;
+            while (p < v.size()) {
+                size_t q = v.find(',', p);
+                if (q == std::string::npos) q = v.size();
+                if (q > p) ids.push_back(std::atoi(v.substr(p, q - p).c_str()));
+                p = q + 1;
+            }
+        }
+    } else if (hvrt_device_count() > 1) {
+        const int n = hvrt_device_count();
+        for (int i = 0; i < n; ++i) ids.push_back(i);
+    }
+    if (const char* e = std::getenv("HVRT_GROUP_MIN_PIXELS")) group_min_pixels_ = (size_t)std::strtoull(e, nullptr, 10);
+    if (ids.size() > 1) {
+        if (hvrt_group_create(&group_, ids.data(), (int)ids.size()) != HVRT_OK)
+            throw std::runtime_error(std::string("hvrt_group_create: ") + hvrt_group_last_error(nullptr));
+        ctx_ = hvrt_group_member(group_, 0);
+        LOG_INFO("[HipVoxelGrid] scene spans {} devices ({} transport)", ids.size(), hvrt_group_transport(group_));
+        return;
+    }
+    if (hvrt_create(&ctx_, ids.empty() ? device_id : ids[0]) != HVRT_OK) raise(nullptr, "hvrt_create");
 }
 
-HipScene::~HipScene() { hvrt_destroy(ctx_); }
+HipScene::~HipScene() {
+    if (group_) hvrt_group_destroy(group_);     // owns the contexts
+    else hvrt_destroy(ctx_);
+}
+
+void HipScene::replicate() {
+    if (group_ && hvrt_group_replicate_scene(group_) != HVRT_OK)
+        throw std::runtime_error(std::string("hvrt_group_replicate_scene: ") + hvrt_group_last_error(group_));
+}
+
+bool HipScene::spansDevices(int width, int height) const {
+    return group_ && (size_t)width * (size_t)height >= group_min_pixels_;
+}
+
+int HipScene::deviceCount() const { return group_ ? hvrt_group_size(group_) : 1; }
 
 void HipScene::setTriangles(const std::vector<Triangle>& tris) {
     tris_ = tris;
@@ -44,6 +88,7 @@ void HipScene::setTriangles(const std::vector<Triangle>& tris) {
 
 void HipScene::buildGrid(int nx, int ny, int nz, const Vec3& mn, const Vec3& mx, const Vec3& vs) {
     ck(ctx_, hvrt_build_grid(ctx_, nx, ny, nz, &mn.x, &mx.x, &vs.x), "hvrt_build_grid");
+    replicate();
 }
 
 void HipScene::computeBounds(const float* xyz, size_t n, Vec3& mn, Vec3& mx) {
@@ -81,6 +126,7 @@ void HipScene::setGrid(const VoxelGrid& g) {
     offsets[nvox] = (uint32_t)indices.size();
     ck(ctx_, hvrt_set_grid_csr(ctx_, g.nx, g.ny, g.nz, &g.minBound.x, &g.maxBound.x, &g.voxelSize.x, offsets.data(),
                                indices.empty() ? nullptr : indices.data()), "hvrt_set_grid_csr");
+    replicate();
 }
 
 VoxelGrid HipScene::downloadGrid() const {
@@ -137,13 +183,20 @@ std::vector<Vec3> HipVoxelRayTracer::render(const Camera& cam, int width, int he
     // PCIe, and the reference's render() returns colours only; the hit COUNT it logs comes from the device
     if (keep_hit_ids_) hit_ids_.assign((size_t)width * height, HVRT_MISS); else hit_ids_.clear();
     uint64_t counters[2] = { 0, 0 };
-    LOG_INFO("[{}] Rendering {}x{} image...", getMethodName(), width, height);
-    ck(scene_->handle(), hvrt_render(scene_->handle(), &fr, width, height, 1, 0, &frame[0].x,
-                                     keep_hit_ids_ ? hit_ids_.data() : nullptr, nullptr, counters), "hvrt_render");
+    uint64_t hits = 0;
+    if (scene_->spansDevices(width, height) && !keep_hit_ids_) {
+        // row tiles over every device of the scene, slabs gathered on the first (include/hvrt.h, group section)
+        LOG_INFO("[{}] Rendering {}x{} image on {} devices...", getMethodName(), width, height, scene_->deviceCount());
+        if (hvrt_group_render(scene_->group(), &fr, width, height, 1, 0, &frame[0].x, counters, &hits) != HVRT_OK)
+            throw std::runtime_error(std::string("hvrt_group_render: ") + hvrt_group_last_error(scene_->group()));
+    } else {
+        LOG_INFO("[{}] Rendering {}x{} image...", getMethodName(), width, height);
+        ck(scene_->handle(), hvrt_render(scene_->handle(), &fr, width, height, 1, 0, &frame[0].x,
+                                         keep_hit_ids_ ? hit_ids_.data() : nullptr, nullptr, counters), "hvrt_render");
+        ck(scene_->handle(), hvrt_last_hit_count(scene_->handle(), &hits), "hvrt_last_hit_count");
+    }
     voxels_ = counters[0];
     tests_ = counters[1];
-    uint64_t hits = 0;
-    ck(scene_->handle(), hvrt_last_hit_count(scene_->handle(), &hits), "hvrt_last_hit_count");
     const double total = (double)width * height;
     // same statistics lines as OctreeLikeRayTracer.cpp:57-65 (counted once per ray, not twice)
     LOG_INFO("[{}] Rendering complete! kernel {:.3f} ms", getMethodName(), scene_->lastRenderMs());

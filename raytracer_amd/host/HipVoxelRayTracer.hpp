@@ -17,9 +17,14 @@
 #endif
 
 struct hvrt_ctx;
+struct hvrt_group;
 
-// A scene resident on one GPU: triangles + CSR grid.  Shared by tracers so that TraceImageMultiView's
+// A scene resident on the GPU(s): triangles + CSR grid.  Shared by tracers so that TraceImageMultiView's
 // three views (TraceImages.cpp:77-119) reuse one upload / one build.
+// Devices: HVRT_DEVICES in the environment lists them ("0,1,2,3", or "all"); unset, a scene lives on device_id alone
+// when the machine has one GPU and on every visible GPU otherwise.  With more than one, the scene is built on the
+// first and replicated (hvrt_group_replicate_scene), and frames of at least HVRT_GROUP_MIN_PIXELS pixels (default
+// 2^22) are traced by all of them (hvrt_group_render); smaller frames, batched views and single rays stay on the first.
 class HipScene {
 public:
     explicit HipScene(int device_id = 0);
@@ -41,11 +46,18 @@ public:
     VoxelGrid downloadGrid() const;
 
     hvrt_ctx* handle() const { return ctx_; }
+    // the device group when the scene spans several GPUs (nullptr otherwise), and whether a frame of this size uses it
+    hvrt_group* group() const { return group_; }
+    bool spansDevices(int width, int height) const;
+    int deviceCount() const;
     double lastBuildMs() const;
     double lastRenderMs() const;
 
 private:
-    hvrt_ctx* ctx_ = nullptr;
+    void replicate();                  // after every change of mesh or grid
+    hvrt_ctx* ctx_ = nullptr;          // member 0 of the group when there is one
+    hvrt_group* group_ = nullptr;
+    size_t group_min_pixels_ = (size_t)1 << 22;
     std::vector<cg_datastructures::Triangle> tris_;   // host copy (downloadGrid returns them)
 };
 

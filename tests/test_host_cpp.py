@@ -204,3 +204,19 @@ def test_jpg_output_names_are_written_as_ppm_under_a_ppm_name(tmp_path):
     for view in ("front", "side", "top"):
         assert open(tmp_path / f"mv_{view}.ppm", "rb").read(2) == b"P6"
         assert not os.path.exists(tmp_path / f"mv_{view}.jpg")
+
+
+@pytest.mark.gpu
+def test_trace_image_over_a_device_group(tmp_path):
+    """TraceImage(stl, out, HIP_VOXEL) with the scene spanning several devices (HVRT_DEVICES; here three contexts on
+    the one GPU of this box, the copy transport): HipScene replicates the scene, HipVoxelRayTracer::render goes through
+    hvrt_group_render, and the file is byte for byte the one a single device writes."""
+    stl = os.path.join(G, "fixture_binary.stl")
+    out = str(tmp_path) + "/"
+    run("render", stl, "one.ppm", "--outdir", out, "--size", "640x360", "--grid", "32", "--quiet")
+    env = dict(os.environ, HVRT_DEVICES="0,0,0", HVRT_GROUP_MIN_PIXELS="1")
+    p = subprocess.run([EXE, "render", stl, "three.ppm", "--outdir", out, "--size", "640x360", "--grid", "32"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "spans 3 devices (copy transport)" in p.stdout + p.stderr and "on 3 devices" in p.stdout + p.stderr
+    assert open(tmp_path / "one.ppm", "rb").read() == open(tmp_path / "three.ppm", "rb").read()
