@@ -103,6 +103,12 @@ struct hvrt_ctx {
     bool adaptive_split = true;    // HVRT_TILE_SPLIT=0 leaves every tile to k_render
     bool cost_valid = false;
     int cost_key[8] = {};
+    // the order of the NEXT launch of the same shape is built right behind a launch (queued while its kernel runs, so
+    // the three small kernels cost their run time and not three launch latencies in front of the next traversal);
+    // likewise the reset of the queue head and of the next launch's cost sum
+    bool order_ahead = false;      // tile_order / split_tiles hold the order for a launch with cost_key
+    bool order_may_split = false;  // ... built with the hand-over of over-long tiles to k_render_split
+    bool queue_clean = false;      // tile_counter and cost_sum[cost_parity] are zero
     unsigned long long* counters = nullptr;   // 2 x u64
     void* out_buf[3] = {};  uint64_t out_cap[3] = {};   // rgb / hit / t staging for host-facing render
     void* io_buf[3] = {};   uint64_t io_cap[3] = {};    // trace staging: origins / dirs / hits
@@ -948,7 +954,8 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     if (int r = ensure<uint32_t>(c, c->split_tiles, c->split_tiles_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->abandoned, c->abandoned_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, 2 * (order_blocks + 1))) return r;
-    const bool reuse = c->adaptive_order && c->cost_valid && !grew && memcmp(key, c->cost_key, sizeof key) == 0;
+    const bool reuse = c->adaptive_order && c->cost_valid && c->order_ahead && !grew && memcmp(key, c->cost_key, sizeof key) == 0;
+    c->order_ahead = false;
 
     RenderArgs ra;
     ra.frames = ds; ra.n_frames = n_frames;
@@ -968,17 +975,16 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     ra.n_abandoned = c->tile_counter + 1;
     ra.abort_ticks = c->abort_ticks;
     ra.tile_cost = c->tile_cost;
-    unsigned long long* prev_sum = c->cost_sum + c->cost_parity;
-    c->cost_parity ^= 1;
     ra.cost_sum = c->cost_sum + c->cost_parity;
     ra.seg_slots = nullptr; ra.seg = 0;
-    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // queue head, abandoned count, [8..15] the heads of segment launches
-    HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    if (!c->queue_clean) {
+        HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // queue head, abandoned count, [8..15] the heads of segment launches
+        HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
+    }
+    c->queue_clean = false;
     if (reuse && n_tiles) {
-        const bool may_split = c->adaptive_split && *(volatile uint32_t*)c->split_hint != 0u;
-        HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, prev_sum, c->n_cus, may_split, c->order_blocks,
-                                      c->tile_order, c->split_tiles, c->split_hint_dev, s));
+        const bool may_split = c->order_may_split;
         if (may_split) {
             // the tiles too long for one wave go first and beside the others, on the second stream
             HIP_TRY(c, hipEventRecord(c->ev_split_fork, s));
@@ -1018,6 +1024,19 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s));
         }
     }
+    // behind the traversal: the order for the next launch of this shape from the durations this one records, and the
+    // clean queue head / cost sum that launch starts from
+    if (c->adaptive_order && n_tiles) {
+        const bool may_split = c->adaptive_split && *(volatile uint32_t*)c->split_hint != 0u;
+        HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, ra.cost_sum, c->n_cus, may_split, c->order_blocks,
+                                      c->tile_order, c->split_tiles, c->split_hint_dev, s));
+        c->order_ahead = true;
+        c->order_may_split = may_split;
+    }
+    c->cost_parity ^= 1;
+    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));
+    HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity, 0, sizeof(unsigned long long), s));
+    c->queue_clean = true;
     HIP_TRY(c, hipEventRecord(c->ev[7], s));
     memcpy(c->cost_key, key, sizeof key);
     c->cost_valid = true;

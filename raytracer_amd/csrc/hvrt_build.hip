@@ -107,17 +107,29 @@ __device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uin
     const int lane = threadIdx.x & 63;
     const unsigned long long S = __ballot(act);
     if (S == 0) return;
-    const uint32_t fprev = __shfl_up(f, 1);
+    // the word a lane adds to: the voxel's counter -- or, with 16-bit counters, the word that holds it and its x
+    // neighbour's, so that a run of lanes walking along x is still ONE atomic (two different voxels of one word
+    // would otherwise be two atomics on the same address, which the L2 serialises)
+    const uint32_t key = MODE == COUNT16 ? f >> 1 : f;
+    const uint32_t kprev = __shfl_up(key, 1);
     const bool prev_act = lane > 0 && ((S >> (lane - 1)) & 1ull);
-    const unsigned long long H = __ballot(act && (!prev_act || fprev != f));
+    const unsigned long long H = __ballot(act && (!prev_act || kprev != key));
     // my run's first lane: the highest head at or below me
     const unsigned long long below = H & (~0ull >> (63 - lane));
     const int hl = act ? 63 - __builtin_clzll(below) : lane;
+    const unsigned long long odd = MODE == COUNT16 ? __ballot(act && (f & 1u)) : 0ull;
     uint32_t base = 0;
     if (act && hl == lane) {
         const unsigned long long stop = (H | ~S) & ~(~0ull >> (63 - lane));   // next head or inactive lane above me
-        const uint32_t len = (uint32_t)((stop ? __builtin_ctzll(stop) : 64) - lane);
-        base = bump<MODE>(cnt, f, len);
+        const int end = stop ? __builtin_ctzll(stop) : 64;
+        const uint32_t len = (uint32_t)(end - lane);
+        if (MODE == COUNT16) {
+            const unsigned long long run = (end == 64 ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+            const uint32_t hi = (uint32_t)__builtin_popcountll(odd & run);
+            atomicAdd(&cnt[key], (len - hi) | (hi << 16));
+        } else {
+            base = bump<MODE>(cnt, f, len);
+        }
     }
     if (MODE == FILL) {
         base = __shfl(base, hl);
@@ -271,7 +283,9 @@ constexpr int SCAN_WAVES = SCAN_CHUNK / 2048;       // 16 waves of 2048 counters
 // occ_bits (nullable): one bit per voxel, "has a list" -- the counters are in registers here anyway, and the
 // distance field's x pass then reads 1/32 of what the offsets would cost it.
 // NARROW: the counters come from the 16-bit array (four per 8-byte load) and the offsets go to cnt4, which nothing
-// has written before (out of place: no memset of the 32-bit array, and half the bytes to read).
+// has written before (out of place: no memset of the 32-bit array, and half the bytes to read).  (Eight counters per
+// 16-byte load and lane -- rows of 512 -- were slower, 2.12 against 1.70 ms at 1024^3: a lane then stores two
+// neighbouring 16-byte pieces, and a wave's store instruction covers its 2 KiB with gaps.)
 template <bool NARROW>
 __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cnt4, const uint2* __restrict__ cnt16,
                                                           uint64_t* __restrict__ status,
@@ -915,6 +929,118 @@ __global__ __launch_bounds__(256) void k_dist_sweep(uint8_t* __restrict__ dist, 
     }
 }
 
+// The same sweep with the line cut into four segments, one per wave of the workgroup (the four waves share their 64
+// lines): a one-dimensional city-block transform is d[i] = min_j (v[j] + |i - j|), a min-reduction, so what a segment
+// contributes to the lines' other segments is two numbers -- min_j (v[j] + distance to the segment's last / first
+// voxel) -- found in one pass of independent loads; after a barrier every wave knows what arrives at its segment from
+// the left and from the right and runs the forward / backward chains over its own quarter only.  Four times the waves
+// and a quarter of the chain: at 256^3 a sweep is 65 536 lines, 1024 waves of 256-step chains as one wave per line set.
+template <int W>
+__global__ __launch_bounds__(256) void k_dist_sweep_seg(uint8_t* __restrict__ dist, uint64_t n_lines, uint64_t inner,
+                                                        uint64_t outer_stride, uint64_t stride, uint32_t n) {
+    using T = typename DistWord<W>::T;
+    constexpr uint32_t U = 16, FAR = 1u << 20;
+    constexpr int S = 4;
+    __shared__ uint32_t s_last[S][W][64], s_first[S][W][64];
+    const int seg = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t line = (uint64_t)blockIdx.x * 64u + (uint32_t)lane;     // in units of W lines
+    const bool in = line < n_lines;
+    const uint64_t first = (in ? line : 0) * W;
+    uint8_t* p = dist + (first % inner) + (first / inner) * outer_stride;
+    auto at = [&](uint32_t i) -> T& { return *reinterpret_cast<T*>(p + (uint64_t)i * stride); };
+    const uint32_t len = (n + S - 1) / S;
+    const uint32_t i0 = (uint32_t)seg * len < n ? (uint32_t)seg * len : n, i1 = i0 + len < n ? i0 + len : n;
+    // what this segment sends on: to its last voxel (for the segments after it) and to its first (for those before)
+    uint32_t to_last[W], to_first[W];
+#pragma unroll
+    for (int b = 0; b < W; ++b) { to_last[b] = FAR; to_first[b] = FAR; }
+    if (in) {
+        uint32_t i = i0;
+        for (; i + U <= i1; i += U) {
+            uint32_t v[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) v[k] = at(i + k);
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+#pragma unroll
+                for (int b = 0; b < W; ++b) {
+                    const uint32_t vb = (v[k] >> (8 * b)) & 0xFFu;
+                    const uint32_t a = vb + (i1 - 1u - (i + k)), c = vb + (i + k - i0);
+                    to_last[b] = a < to_last[b] ? a : to_last[b];
+                    to_first[b] = c < to_first[b] ? c : to_first[b];
+                }
+        }
+        for (; i < i1; ++i) {
+            const uint32_t v = at(i);
+#pragma unroll
+            for (int b = 0; b < W; ++b) {
+                const uint32_t vb = (v >> (8 * b)) & 0xFFu;
+                const uint32_t a = vb + (i1 - 1u - i), c = vb + (i - i0);
+                to_last[b] = a < to_last[b] ? a : to_last[b];
+                to_first[b] = c < to_first[b] ? c : to_first[b];
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < W; ++b) { s_last[seg][b][lane] = to_last[b]; s_first[seg][b][lane] = to_first[b]; }
+    __syncthreads();
+    if (!in || i0 >= i1) return;
+    auto seg_len = [&](int k) { const uint32_t a = (uint32_t)k * len < n ? (uint32_t)k * len : n; return (a + len < n ? a + len : n) - a; };
+    uint32_t run[W];
+    // forward: what reaches my first voxel from the left, then the chain over my segment
+#pragma unroll
+    for (int b = 0; b < W; ++b) {
+        uint32_t c = FAR;
+        for (int k = 0; k < seg; ++k) {
+            const uint32_t through = c + seg_len(k), from = s_last[k][b][lane] + 1u;
+            c = through < from ? through : from;
+        }
+        run[b] = (c > 256u ? 256u : c) - 1u;        // so that run + 1 is the arriving value (at least 1)
+    }
+    uint32_t i = i0;
+    for (; i + U <= i1; i += U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = at(i + k);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t o = dist_relax<W>(run, v[k]);
+            if (o != v[k]) at(i + k) = (T)o;
+        }
+    }
+    for (; i < i1; ++i) {
+        const uint32_t v = at(i);
+        const uint32_t o = dist_relax<W>(run, v);
+        if (o != v) at(i) = (T)o;
+    }
+    // backward
+#pragma unroll
+    for (int b = 0; b < W; ++b) {
+        uint32_t c = FAR;
+        for (int k = S - 1; k > seg; --k) {
+            const uint32_t through = c + seg_len(k), from = s_first[k][b][lane] + 1u;
+            c = through < from ? through : from;
+        }
+        run[b] = (c > 256u ? 256u : c) - 1u;
+    }
+    i = i1;
+    for (; i >= i0 + U; i -= U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) v[k] = at(i - 1 - k);
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const uint32_t o = dist_relax<W>(run, v[k]);
+            if (o != v[k]) at(i - 1 - k) = (T)o;
+        }
+    }
+    for (; i > i0; --i) {
+        const uint32_t v = at(i - 1);
+        const uint32_t o = dist_relax<W>(run, v);
+        if (o != v) at(i - 1) = (T)o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // mesh bounds (computeMeshBounds, SceneCreator.cpp:49-84)
 // ------------------------------------------------------------------------------------------
@@ -1076,16 +1202,29 @@ hipError_t launch_distance_field(const uint32_t* offsets, const uint32_t* occ_bi
     // four lines per lane where line starts and strides are multiples of 4 (dist itself is 256-B aligned) -- but
     // only when that still leaves every SIMD a few waves: a sweep is a serial chain per lane, and at 256^3 four
     // lines per lane are 256 waves for 1024 SIMDs
-    constexpr uint64_t SWEEP_WIDE_MIN = 4 * 64 * 1024;
+    // lines of at least SWEEP_SEG_MIN voxels are swept in four segments by the four waves of a workgroup -- while one
+    // wave per 64 line units would leave the SIMDs short of waves; beyond that the whole-line kernel already runs at
+    // the memory's pace and reads every voxel once less (1024^3: 4.2 against 4.5 ms for the derived data)
+    constexpr uint64_t SWEEP_WIDE_MIN = 4 * 64 * 1024, SWEEP_SEG_MIN = 64, SWEEP_SEG_MAX_UNITS = 4 * 64 * 1024;
     if (ny > 1) {
         const uint64_t lines = nx * nz;
-        if (nx % 4 == 0 && lines >= SWEEP_WIDE_MIN) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, nx, nx * ny, nx, (uint32_t)ny);
-        else k_dist_sweep<1><<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, nx, nx * ny, nx, (uint32_t)ny);
+        const bool wide = nx % 4 == 0 && lines >= SWEEP_WIDE_MIN;
+        const uint64_t units = wide ? lines / 4 : lines;
+        if (ny >= SWEEP_SEG_MIN && units < SWEEP_SEG_MAX_UNITS) {
+            if (wide) k_dist_sweep_seg<4><<<(unsigned)((units + 63) / 64), 256, 0, s>>>(dist, units, nx, nx * ny, nx, (uint32_t)ny);
+            else k_dist_sweep_seg<1><<<(unsigned)((units + 63) / 64), 256, 0, s>>>(dist, units, nx, nx * ny, nx, (uint32_t)ny);
+        } else if (wide) k_dist_sweep<4><<<(unsigned)((units + 255) / 256), 256, 0, s>>>(dist, units, nx, nx * ny, nx, (uint32_t)ny);
+        else k_dist_sweep<1><<<(unsigned)((units + 255) / 256), 256, 0, s>>>(dist, units, nx, nx * ny, nx, (uint32_t)ny);
     }
     if (nz > 1) {
         const uint64_t lines = nx * ny;
-        if (lines % 4 == 0 && lines >= SWEEP_WIDE_MIN) k_dist_sweep<4><<<(unsigned)((lines / 4 + 255) / 256), 256, 0, s>>>(dist, lines / 4, lines, 0, lines, (uint32_t)nz);
-        else k_dist_sweep<1><<<(unsigned)((lines + 255) / 256), 256, 0, s>>>(dist, lines, lines, 0, lines, (uint32_t)nz);
+        const bool wide = lines % 4 == 0 && lines >= SWEEP_WIDE_MIN;
+        const uint64_t units = wide ? lines / 4 : lines;
+        if (nz >= SWEEP_SEG_MIN && units < SWEEP_SEG_MAX_UNITS) {
+            if (wide) k_dist_sweep_seg<4><<<(unsigned)((units + 63) / 64), 256, 0, s>>>(dist, units, lines, 0, lines, (uint32_t)nz);
+            else k_dist_sweep_seg<1><<<(unsigned)((units + 63) / 64), 256, 0, s>>>(dist, units, lines, 0, lines, (uint32_t)nz);
+        } else if (wide) k_dist_sweep<4><<<(unsigned)((units + 255) / 256), 256, 0, s>>>(dist, units, lines, 0, lines, (uint32_t)nz);
+        else k_dist_sweep<1><<<(unsigned)((units + 255) / 256), 256, 0, s>>>(dist, units, lines, 0, lines, (uint32_t)nz);
     }
     return hipGetLastError();
 }

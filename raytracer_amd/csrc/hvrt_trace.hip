@@ -790,9 +790,15 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
 // exit condition (tile >= n_tiles) is reached by every wave whatever the grid size.
 // ABORT: the variant for launches without tile history (see "gives up" below); launches with history run the
 // plain one -- the bookkeeping costs 4 % of a config 2 frame, and history already sends long tiles elsewhere.
+// Eight waves per SIMD (64 VGPRs): the kernel is bound by VALU issue with long dependent chains, and every further
+// resident wave fills issue slots -- 5 / 6 / 7 / 8 waves: 91.4 / 81.8 / 78.4 / 74.2 ms on config 4, 1.775 -> 1.759 ms on
+// config 2.  At 64 registers the plain kernel keeps 24 bytes per lane in scratch (70 registers and none at 7 waves),
+// but what the allocator parks there is per-tile state -- one dword stored before the tile loop, one 16-byte store and
+// reload per tile, nothing inside the walk or the list loops (scripts/kernel_resources.sh; grep scratch_ in the
+// assembly) -- so the extra traffic is a few bytes per pixel into L2, on a kernel that uses 4 % of the HBM bandwidth.
 template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 #ifndef HVRT_RENDER_WAVES
-#define HVRT_RENDER_WAVES 7
+#define HVRT_RENDER_WAVES 8
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render(SceneDev sc, RenderArgs ra) {
     __shared__ float4 lds_win[4][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
@@ -1221,7 +1227,7 @@ hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsig
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
                               uint32_t* wants_split, hipStream_t s) {
     const unsigned blocks = (n_tiles + 255u) / 256u;
-    const uint32_t slots = (uint32_t)n_cus * 28u;          // k_render runs 7 waves per SIMD
+    const uint32_t slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
     may_split = may_split && n_tiles <= 0x0FFFFFFFu;       // 16 items per tile in a 32-bit count
     k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count);
     k_order_scan<<<2, 1024, 0, s>>>(block_count, blocks, may_split, wants_split);

@@ -163,10 +163,16 @@ def test_ingest_cpu_built_csr_round_trip(ctx):
 
 
 @pytest.mark.parametrize("dims,fill", [((520, 3, 2), 0.01), ((1028, 2, 1), 0.003), ((70, 5, 3), 0.02), ((256, 9, 7), 0.0),
-                                       ((64, 64, 64), 0.0005), ((300, 1, 1), 0.01), ((4, 300, 2), 0.02), ((16388, 1, 2), 0.0002)])
+                                       ((64, 64, 64), 0.0005), ((300, 1, 1), 0.01), ((4, 300, 2), 0.02), ((16388, 1, 2), 0.0002),
+                                       # sweeps cut into four segments per line (lines of >= 64 voxels): uneven segment
+                                       # lengths, a last segment that is empty (65 = 17 + 17 + 17 + 14; 129, 257), values
+                                       # that saturate at 255 across segments, and the packed form (>= 262 144 lines)
+                                       ((8, 100, 67), 0.001), ((12, 65, 130), 0.0003), ((4, 257, 129), 0.00005), ((3, 1100, 2), 0.0004),
+                                       ((512, 512, 64), 0.00002), ((516, 70, 512), 0.00001), ((64, 66, 70), 0.0)])
 def test_distance_field_of_ingested_grids(ctx, dims, fill):
     """Every kernel variant of the empty-space distance field (4-voxel and 1-voxel x pass, packed and plain
-    sweeps, saturation at 255, an empty grid) against plain numpy sweeps, on synthetic occupancy."""
+    sweeps, whole-line and segmented, saturation at 255, an empty grid) against plain numpy sweeps, on synthetic
+    occupancy."""
     nx, ny, nz = dims
     rng = np.random.default_rng(nx * 31 + ny * 7 + nz)
     occ = rng.random(nx * ny * nz) < fill
