@@ -8,6 +8,8 @@
 // Shaders.cpp:4-22).  Compile with -ffp-contract=off: a*b+c must stay v_mul + v_add.
 #include "hvrt_internal.hpp"
 
+#include <stddef.h>
+
 #include <float.h>
 #include <limits.h>
 
@@ -748,10 +750,23 @@ template <bool COUNT, bool INLINE, bool NEAREST, int RAYS, bool ABORT>
 __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArgs& ra, const hvrt_camera_frame* __restrict__ cf,
                                              uint32_t tx, uint32_t ty, int lane, int px_x, int px_y, bool alive,
                                              float4* __restrict__ win, long long wall0, PixelResult& out) {
-    const V3 org = { cf->origin[0], cf->origin[1], cf->origin[2] };          // wave-uniform: scalar loads
-    const V3 ll = { cf->lower_left[0], cf->lower_left[1], cf->lower_left[2] };
-    const V3 hor = { cf->horizontal[0], cf->horizontal[1], cf->horizontal[2] };
-    const V3 ver = { cf->vertical[0], cf->vertical[1], cf->vertical[2] };
+    // The frame is wave-uniform and nothing writes it while the kernel runs, but the compiler cannot see the second
+    // part (the tile loop stores pixels) and would fetch it with vector loads into twelve vector registers that stay
+    // live across the walk -- four of them in scratch at 64 registers.  Read through the constant address space it
+    // arrives by scalar loads in scalar registers; and it is read again for every sample (the opaque copy of the
+    // pointer below), because nine scalar registers held across the walk are spilled into lanes of a vector register
+    // and come back through v_readlane inside the walk's loops.
+    typedef const __attribute__((address_space(4))) float* const_floats;
+    static_assert(sizeof(hvrt_camera_frame) == 48 && offsetof(hvrt_camera_frame, lower_left) == 12 &&
+                  offsetof(hvrt_camera_frame, horizontal) == 24 && offsetof(hvrt_camera_frame, vertical) == 36, "twelve consecutive floats");
+    const uint64_t cf_bits = (uint64_t)(uintptr_t)cf;       // the same for every lane: say so
+    const uint64_t cf_uniform = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cf_bits) |
+                                ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cf_bits >> 32)) << 32);
+    const_floats cfs = (const_floats)cf_uniform;
+    V3 org = { cfs[0], cfs[1], cfs[2] };
+    // (the origin is an operand of every ray / triangle test: in vector registers, where the walk can use it without a
+    // second scalar operand in one instruction)
+    asm volatile("" : "+v"(org.x), "+v"(org.y), "+v"(org.z));
     V3 acc = { 0.0f, 0.0f, 0.0f };
     out.hit = HVRT_MISS; out.t = FLT_MAX; out.nv = 0; out.nt = 0;
     for (int s = 0; s < ra.spp; ++s) {
@@ -763,6 +778,8 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
         if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
         const float u = ((float)x + jx) / ra.width_f;
         const float v = ((float)y + jy) / ra.height_f;
+        asm volatile("" : "+s"(cfs));
+        const V3 ll = { cfs[3], cfs[4], cfs[5] }, hor = { cfs[6], cfs[7], cfs[8] }, ver = { cfs[9], cfs[10], cfs[11] };
         const V3 d = normalize(sub(add(add(ll, mul(hor, u)), mul(ver, v)), org));
         TraceResult r;
         // the wave-synchronous walk wants every lane of the wave in the call, with or without a ray (alive);
@@ -791,11 +808,9 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
 // ABORT: the variant for launches without tile history (see "gives up" below); launches with history run the
 // plain one -- the bookkeeping costs 4 % of a config 2 frame, and history already sends long tiles elsewhere.
 // Eight waves per SIMD (64 VGPRs): the kernel is bound by VALU issue with long dependent chains, and every further
-// resident wave fills issue slots -- 5 / 6 / 7 / 8 waves: 91.4 / 81.8 / 78.4 / 74.2 ms on config 4, 1.775 -> 1.759 ms on
-// config 2.  At 64 registers the plain kernel keeps 24 bytes per lane in scratch (70 registers and none at 7 waves),
-// but what the allocator parks there is per-tile state -- one dword stored before the tile loop, one 16-byte store and
-// reload per tile, nothing inside the walk or the list loops (scripts/kernel_resources.sh; grep scratch_ in the
-// assembly) -- so the extra traffic is a few bytes per pixel into L2, on a kernel that uses 4 % of the HBM bandwidth.
+// resident wave fills issue slots -- 5 / 6 / 7 / 8 waves: 91.4 / 81.8 / 78.4 / 73.6 ms on config 4.  The plain kernel
+// fits in 63 registers with no scratch (scripts/kernel_resources.sh) since the camera frame stopped living in twelve
+// vector registers across the walk (render_pixel); the counting variants keep 24-40 bytes per lane there.
 template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 #ifndef HVRT_RENDER_WAVES
 #define HVRT_RENDER_WAVES 8

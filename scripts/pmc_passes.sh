@@ -1,22 +1,28 @@
 #!/bin/bash
-# Counter passes for the hvrt kernels on config 2 (each pass its own rocprofv3 run, as gpurun requires).
-# usage: scripts/pmc_passes.sh <outdir-name under gpurun_out>
+# Counter passes for the hvrt kernels (each pass its own rocprofv3 run, as gpurun requires; limits per pass: 8 SQ, 4 TCC
+# with FETCH_SIZE = 3 and WRITE_SIZE = 2, 4 TCP, 2 TA, 2 TD, 2 GRBM).
+#   scripts/pmc_passes.sh <outdir-name under gpurun_out> render   -> config 2 traversal (scripts/prof_render.py)
+#   scripts/pmc_passes.sh <outdir-name under gpurun_out> build    -> config 5 voxel build (scripts/prof_build.py c5 3)
 set -u
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$1
+what=${2:-render}
 mkdir -p $O
+cd /tmp
 i=0
-for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
-         "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY" \
-         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
-         "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum" "GRBM_GUI_ACTIVE GRBM_TA_BUSY"; do
+if [ "$what" = render ]; then
+  prog="scripts/prof_render.py"
+  passes=("FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
+          "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY" \
+          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+          "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum" "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum" "GRBM_GUI_ACTIVE GRBM_TA_BUSY")
+else
+  prog="scripts/prof_build.py c5 3"
+  passes=("FETCH_SIZE" "WRITE_SIZE" "TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE")
+fi
+for P in "${passes[@]}"; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $O/p$i -- python3 scripts/prof_render.py > $O/p$i.log 2>&1 || { echo "pass $i ($P) failed"; tail -3 $O/p$i.log; }
+  timeout -s KILL 180 rocprofv3 --pmc $P --output-format csv -d $O/p$i -- python3 $GRAFT_REPO_ROOT/$prog > $O/p$i.log 2>&1 || { echo "pass $i ($P) failed"; tail -3 $O/p$i.log; exit 1; }
 done
-python3 scripts/parse_pmc.py $O > $O/summary.json
-python3 - <<PY
-import json
-r=json.load(open("$O/summary.json"))
-for k,v in r.items():
-    if "render" in k or "sort" in k: print(k, {c:round(x["mean"]/1e6,2) for c,x in v.items()})
-PY
+python3 $GRAFT_REPO_ROOT/scripts/parse_pmc.py $O > $O/summary.json
+echo "$what: $i passes done"
