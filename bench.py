@@ -118,8 +118,8 @@ def render_roofline(prof, k_ms, rays, bytes_per_ray):
         out.update({"bound": bound.replace("_frac", ""), "achieved": cands[bound], "peak": 1.0,
                     "unit": "busy clocks of the binding unit per kernel clock", "frac": cands[bound]})
         out["candidates"] = cands
-        for k in ("valu_insts_per_launch", "valu_clocks_per_inst", "vector_loads_per_launch", "kernel_cycles", "profiled_kernel_ms",
-                  "l2_hit_rate", "source"):
+        for k in ("valu_issue_frac_mix", "valu_issue_frac_mix_raw", "valu_insts_per_launch", "valu_clocks_per_inst_floor", "valu_clocks_per_inst",
+                  "vector_loads_per_launch", "vector_loads_per_tile", "kernel_cycles", "l2_hit_rate", "source", "busy_source"):
             if k in prof:
                 out[k] = prof[k]
     else:

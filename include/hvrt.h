@@ -84,7 +84,8 @@ typedef struct hvrt_timings {
     float build_fill_ms;
     float build_sort_ms;
     float build_expand_ms;  /* libhvrt's own acceleration data: distance field, face bits, per-reference records */
-    float render_ms;        /* last hvrt_render* / hvrt_trace_device: tile ordering + traversal kernel */
+    float render_ms;        /* last hvrt_render* / hvrt_trace_device: the traversal kernels (the tile order of the next
+                             * launch of the same shape is built behind them and is not in this figure) */
     float trace_ms;         /* last hvrt_trace */
 } hvrt_timings;
 

@@ -1024,6 +1024,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s));
         }
     }
+    HIP_TRY(c, hipEventRecord(c->ev[7], s));       // render_ms: the traversal (k_render, and k_render_split beside or behind it)
     // behind the traversal: the order for the next launch of this shape from the durations this one records, and the
     // clean queue head / cost sum that launch starts from
     if (c->adaptive_order && n_tiles) {
@@ -1037,7 +1038,6 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));
     HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity, 0, sizeof(unsigned long long), s));
     c->queue_clean = true;
-    HIP_TRY(c, hipEventRecord(c->ev[7], s));
     memcpy(c->cost_key, key, sizeof key);
     c->cost_valid = true;
     c->render_pending = true;

@@ -815,7 +815,7 @@ template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 #ifndef HVRT_RENDER_WAVES
 #define HVRT_RENDER_WAVES 8
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render(SceneDev sc, RenderArgs ra) {
+__device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArgs& ra) {
     __shared__ float4 lds_win[4][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
     // (the lane number is worked out where it is needed, lane_now(): a register held for it would be spilled)
     float4* const win = lds_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
@@ -951,6 +951,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER
             atomicAdd(&ra.counters[1], (unsigned long long)tot_nt);
         }
     }
+}
+
+template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render(SceneDev sc, RenderArgs ra) {
+    render_tiles<COUNT, INLINE, NEAREST, ABORT>(sc, ra);
+}
+// The same code under a second name, for launches over a range of the queue's slots (RenderArgs::seg_slots, the host
+// path's half frames): a kernel trace then lists whole-frame launches and part launches separately instead of
+// averaging them into one row.
+template <bool COUNT, bool INLINE, bool NEAREST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render_segment(SceneDev sc, RenderArgs ra) {
+    render_tiles<COUNT, INLINE, NEAREST, false>(sc, ra);
 }
 
 // ---- tiles too long for one wave ------------------------------------------------------------------------
@@ -1209,6 +1221,7 @@ hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bo
     const bool il = sc.ref_rec != nullptr;
     const unsigned nb = (unsigned)blocks;
 #define HVRT_LAUNCH3(C, I, N) do { if (abortable) k_render<C, I, N, true><<<nb, 256, 0, s>>>(sc, ra); \
+                                   else if (ra.seg_slots) k_render_segment<C, I, N><<<nb, 256, 0, s>>>(sc, ra); \
                                    else k_render<C, I, N, false><<<nb, 256, 0, s>>>(sc, ra); } while (0)
 #define HVRT_LAUNCH(C, I) do { if (ra.nearest) HVRT_LAUNCH3(C, I, true); else HVRT_LAUNCH3(C, I, false); } while (0)
     if (ra.counters) { if (il) HVRT_LAUNCH(true, true); else HVRT_LAUNCH(true, false); }

@@ -9,8 +9,11 @@ export TMPDIR=/tmp
 if [ "$step" = pmc ]; then
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render render || exit 1
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_build build || exit 1
+  $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c4 render_c4 || exit 1
+  $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c3 render_c3 || exit 1
   exit 0
 fi
+rm -rf $O/kt_bench $O/kt_c3 $O/kt_c4 $O/kt_c5
 cd $GRAFT_REPO_ROOT
 timeout -k 10 300 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err || { tail -5 $O/bench_c2.err; exit 1; }
 timeout -k 10 300 python bench.py --workload c3 > $O/bench_c3.json 2> $O/bench_c3.err || { tail -5 $O/bench_c3.err; exit 1; }

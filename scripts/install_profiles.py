@@ -12,6 +12,17 @@ P = os.path.join(R, "profiles")
 KERNEL = "k_render<false, true, false, false>"
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 CLK_WAVE_LOAD_X4 = 16.3        # profiles/r2_ubench_l1_rate.txt: coalesced 16-byte-per-lane wave-load, clk per CU
+CLK_VALU_FLOOR = 2.2           # profiles/r2_ubench_valu_rate.txt: a plain VOP1 / VOP2 instruction with >= 2 waves resident
+
+
+def valu_fracs(insts, clk_mix, cyc):
+    """VALU issue as a fraction of the SIMDs' clocks.  The floor prices every instruction at the plain rate (no
+    instruction issues faster), so it cannot overstate; the mix estimate prices the hot loops' STATIC instruction mix
+    (profiles/r2_valu_mix.json) and overstates where the cheap instructions run more often than they are written
+    (it exceeds 1 on configs 3 and 4) -- it is reported capped at 1, with the raw figure beside it."""
+    raw = insts * clk_mix / N_SIMD / cyc
+    return {"valu_issue_frac": round(insts * CLK_VALU_FLOOR / N_SIMD / cyc, 3), "valu_issue_frac_mix": round(min(1.0, raw), 3),
+            "valu_issue_frac_mix_raw": round(raw, 3), "valu_clocks_per_inst_floor": CLK_VALU_FLOOR}
 
 
 def mean_of(k, c):
@@ -35,11 +46,8 @@ if step == "pmc":
         "source": "profiles/r2_pmc_c2.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch of " + KERNEL +
                   "; busy fractions over GRBM_GUI_ACTIVE / 8 XCDs",
         "kernel_cycles": cyc,
-        "profiled_kernel_ms": cyc / 2.4e6,
         "valu_insts_per_launch": m("SQ_INSTS_VALU"), "valu_clocks_per_inst": clk_valu,
-        "valu_issue_frac": round(m("SQ_INSTS_VALU") * clk_valu / N_SIMD / cyc, 3),
-        "valu_issue_frac_at_2clk": round(m("SQ_INSTS_VALU") * 2.0 / N_SIMD / cyc, 3),
-        "valu_issue_frac_at_4clk": round(m("SQ_INSTS_VALU") * 4.0 / N_SIMD / cyc, 3),
+        **valu_fracs(m("SQ_INSTS_VALU"), clk_valu, cyc),
         "salu_insts_per_launch": m("SQ_INSTS_SALU"), "salu_issue_frac": round(m("SQ_INSTS_SALU") / N_CU / cyc, 3),
         "vector_loads_per_launch": m("SQ_INSTS_VMEM_RD"),
         "vector_loads_per_tile": m("SQ_INSTS_VMEM_RD") / (3840 * 2160 / 64),
@@ -47,7 +55,8 @@ if step == "pmc":
         "lds_insts_per_launch": m("SQ_INSTS_LDS") if "SQ_INSTS_LDS" in k else None,
         "td_busy_frac": round(m("TD_TD_BUSY_sum") / N_CU / cyc, 3), "ta_busy_frac": round(m("TA_TA_BUSY_sum") / N_CU / cyc, 3),
         "l2_hit_rate": round(m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum")), 3),
-        "busy_source": "SQ_INSTS_VALU x mean issue clocks (profiles/r2_valu_mix.json, priced by profiles/r2_ubench_valu_rate.txt) / 1024 SIMDs; "
+        "busy_source": "valu_issue_frac: SQ_INSTS_VALU x 2.2 clk (the plain VOP1 / VOP2 rate, profiles/r2_ubench_valu_rate.txt) / 1024 SIMDs, a floor; "
+                       "valu_issue_frac_mix: x the static hot-loop mix's mean issue clocks (profiles/r2_valu_mix.json), capped at 1; "
                        "SQ_INSTS_VMEM_RD x 16.3 clk (profiles/r2_ubench_l1_rate.txt, coalesced 16 B per lane) / 256 CUs; "
                        "SQ_INSTS_SALU / 256 CUs (one scalar unit per CU)",
     }
@@ -64,11 +73,34 @@ if step == "pmc":
         per = {n: {"fetch_x2_MB": 2 * v["FETCH_SIZE"]["mean"] * 1024 / 1e6, "write_MB": pb[n]["WRITE_SIZE"]["mean"] * 1024 / 1e6,
                    "atomics_M": pb[n].get("TCC_ATOMIC_sum", {"mean": 0})["mean"] / 1e6}
                for n, v in pb.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in pb[n]}
-        t["c5"] = {"build_hbm_bytes": (2 * fetch + write) * 1024 / n_builds,
+        csr = ("k_count", "k_scan", "k_fill", "k_rank_sort", "k_sort_long", "__amd_rocclr_fillBufferAligned")
+        csr_bytes = sum((2 * v["FETCH_SIZE"]["sum"] + pb[n]["WRITE_SIZE"]["sum"]) * 1024 for n, v in pb.items()
+                        if n.startswith(csr) and "FETCH_SIZE" in v) / n_builds
+        t["c5"] = {"build_hbm_bytes": csr_bytes,        # the CSR's kernels and memsets: what B_build prices
+                   "build_with_derived_data_hbm_bytes": (2 * fetch + write) * 1024 / n_builds,
                    "build_fetch_size_bytes_raw": fetch * 1024 / n_builds, "build_write_size_bytes": write * 1024 / n_builds,
                    "build_l2_atomics": atom / n_builds, "build_per_kernel_per_launch": per,
-                   "build_source": "profiles/r2_pmc_build_c5.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over every kernel and "
-                                   "runtime fill of a build (3 builds of scripts/prof_build.py c5; set_mesh's kernels excluded)"}
+                   "build_source": "profiles/r2_pmc_build_c5.json: (2 x FETCH_SIZE + WRITE_SIZE) x 1024 summed over the CSR's kernels "
+                                   "(k_count, k_scan*, k_fill, k_rank_sort, k_sort_long) and the runtime's fills, per build (3 builds of "
+                                   "scripts/prof_build.py c5); build_with_derived_data_hbm_bytes adds distance field, face bits, records"}
+    for w, px in (("c3", 3840 * 2160), ("c4", 7680 * 4320)):
+        fp = F + "/pmc_render_" + w + "/summary.json"
+        if not os.path.exists(fp):
+            continue
+        pw = json.load(open(fp))
+        json.dump(pw, open(P + "/r2_pmc_" + w + ".json", "w"), indent=1)
+        kw = [v for n, v in pw.items() if KERNEL in n][0]
+        mw = lambda c: mean_of(kw, c)
+        cw = mw("GRBM_GUI_ACTIVE") / N_XCD
+        t[w] = {"kernel": KERNEL,
+                "k_render_hbm_bytes_per_launch": (2 * mw("FETCH_SIZE") + mw("WRITE_SIZE")) * 1024,
+                "kernel_cycles": cw, "valu_insts_per_launch": mw("SQ_INSTS_VALU"), "valu_clocks_per_inst": clk_valu,
+                **valu_fracs(mw("SQ_INSTS_VALU"), clk_valu, cw),
+                "salu_issue_frac": round(mw("SQ_INSTS_SALU") / N_CU / cw, 3),
+                "vector_loads_per_launch": mw("SQ_INSTS_VMEM_RD"), "vector_loads_per_tile": mw("SQ_INSTS_VMEM_RD") / (px / 64),
+                "vmem_return_frac": round(mw("SQ_INSTS_VMEM_RD") * CLK_WAVE_LOAD_X4 / N_CU / cw, 3),
+                "source": "profiles/r2_pmc_" + w + ".json, priced like c2 (the hot loops are the same code: profiles/r2_valu_mix.json)"}
+        print(w, {k: v for k, v in t[w].items() if not isinstance(v, str)})
     json.dump(t, open(P + "/traffic.json", "w"), indent=1)
     print(json.dumps({k: v for k, v in c2.items() if not isinstance(v, str)}, indent=0))
     if "c5" in t:
@@ -76,9 +108,9 @@ if step == "pmc":
 else:
     for sub, dst in (("kt_bench", "r2_bench_c2_kernel_stats.csv"), ("kt_c3", "r2_bench_c3_kernel_stats.csv"),
                      ("kt_c4", "r2_bench_c4_kernel_stats.csv"), ("kt_c5", "r2_build_c5_kernel_stats.csv")):
-        f = glob.glob(F + "/" + sub + "/*/*kernel_stats.csv")
+        f = sorted(glob.glob(F + "/" + sub + "/*/*kernel_stats.csv"), key=os.path.getmtime)     # a re-run leaves older files behind
         if f:
-            shutil.copy(f[0], P + "/" + dst)
+            shutil.copy(f[-1], P + "/" + dst)
     for src, dst in (("bench_c2.json", "r2_bench_c2.json"), ("bench_c2_under_rocprof.json", "r2_bench_c2_under_rocprof.json"),
                      ("bench_c3.json", "r2_bench_c3.json"), ("bench_c4.json", "r2_bench_c4.json"), ("bench_c5.json", "r2_bench_c5.json")):
         if not os.path.exists(F + "/" + src):
