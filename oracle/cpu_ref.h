@@ -10,14 +10,16 @@
  * /root/reference/RayTracer/).  All arithmetic is IEEE fp32, round-to-nearest-even,
  * no FMA contraction (build with -ffp-contract=off), comparisons with NaN are false.
  *
- * Pinning status (see oracle/README.md and DESIGN.md section "Oracle"):
+ * Pinning status ("Oracle"):
  *   - ray/triangle test, triangle min/max, vector math, Lambert shader, STL ingest:
  *     pinned bit-for-bit against the real reference sources compiled in place
  *     (oracle/_ref, built from GeometryUtils.cpp, Shaders.cpp, STLReader.h, VectorMath.h).
  *   - voxelizer CSR order, DDA init/advance, ray generation, render loop:
  *     SceneCreator.cpp and OctreeLikeRayTracer.cpp need spdlog, which this image lacks,
  *     so they are unbuildable here without a stand-in: PARITY UNPINNED by live execution;
- *     pinned only by the reference run outputs recorded in SURVEY.md Appendix C / section 6.
+ *     pinned only by the reference run outputs recorded in SURVEY.md Appendix C / section 6
+ *     (tests/test_oracle_pinning.py: both recorded runs; tests/test_gpu_recorded_runs.py holds the
+ *     HIP path to the same recorded numbers directly).
  */
 #ifndef ORACLE_CPU_REF_H
 #define ORACLE_CPU_REF_H
