@@ -457,6 +457,26 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_i, 2048 * 6 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_out, 256)) != hipSuccess) return bail("hipMalloc", e);
+    // The reference constructs a tracer per image and renders once (TraceImages.cpp:215-229): what the process pays once
+    // for a traversal kernel's first dispatch is paid here, not inside that one render() (HVRT_WARMUP=0: not at all).
+    const char* warm = getenv("HVRT_WARMUP");
+    if (!warm || atoi(warm) != 0) {
+        if ((e = hipMemsetAsync(c->tile_counter, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
+        if ((e = hipMemsetAsync(c->cost_sum, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
+        if ((e = launch_render_warmup(c->tile_counter, c->cost_sum, c->n_cus, c->stream)) != hipSuccess) return bail("warm-up launches", e);
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
+        // and one pass through the download ring on each of the two streams a frame comes back on
+        const size_t wb = 4 * hvrt_ctx::PIN_CHUNK;
+        void* d_tmp = nullptr;
+        std::vector<char> h_tmp(wb);
+        if ((e = hipMalloc(&d_tmp, wb)) != hipSuccess) return bail("hipMalloc", e);
+        int rc = download(c, h_tmp.data(), d_tmp, wb, c->stream);
+        if (rc == HVRT_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = HVRT_ERR_HIP;
+        if (rc == HVRT_OK) rc = download(c, h_tmp.data(), d_tmp, wb, c->copy_stream);
+        if (rc == HVRT_OK && hipStreamSynchronize(c->copy_stream) != hipSuccess) rc = HVRT_ERR_HIP;
+        (void)hipFree(d_tmp);
+        if (rc != HVRT_OK) { g_create_error = "warm-up of the download ring failed: " + c->error; hvrt_destroy(c); return rc; }
+    }
     *out = c;
     return HVRT_OK;
 }

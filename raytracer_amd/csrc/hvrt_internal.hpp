@@ -141,6 +141,8 @@ hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* 
 int bounds_blocks(uint64_t n_points);
 
 // ---- launchers (hvrt_trace.hip) ----
+// empty launches of the traversal kernels (code resolution, scratch set-up); words: 64 zeroed u32, left zeroed
+hipError_t launch_render_warmup(uint32_t* words, unsigned long long* cost_sum, int n_cus, hipStream_t s);
 // abortable: the kernel may give up on over-long tiles (ra.abandoned); a launch_render_split over that list must follow
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);

@@ -1253,6 +1253,54 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
 
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
+                              uint32_t* wants_split, hipStream_t s);
+hipError_t launch_order_segments(const uint32_t* order, const uint32_t* block_count, uint32_t n_blocks, uint32_t n_tiles,
+                                 uint32_t tiles_x, const uint32_t* row_bounds, int n_seg, uint32_t* seg_slots, hipStream_t s);
+
+// One empty launch of every traversal kernel a first frame can need (reference traversal, per-reference records; with
+// and without the statistics): the runtime resolves a kernel's code and sets up the scratch its private segment needs
+// when it is first dispatched, which cost the first hvrt_render of a process 6 ms of its 11.5 (and the second, which
+// runs other variants, another 5) -- paid in hvrt_create instead, where the runtime's own start-up is 30 times that.
+// words: 64 zeroed device words; the launches find an empty queue (words[40] = 1 tile, all of it "split away";
+// words[41] = 0 tiles for k_render_split; the segment's slot range words[32..33] is empty) and end at once.
+hipError_t launch_render_warmup(uint32_t* words, unsigned long long* cost_sum, int n_cus, hipStream_t s) {
+    // (full-size grids: the runtime sizes a queue's scratch by the waves of the dispatch that needs it)
+    const unsigned nb = (unsigned)n_cus * 8u;
+    const uint32_t one = 1u;
+    hipError_t e = hipMemcpyAsync(words + 40, &one, sizeof one, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    SceneDev sc = {};
+    RenderArgs ra = {};
+    ra.n_frames = 1; ra.width = 8; ra.height = 8; ra.local_rows = 8; ra.slab_rows = 8; ra.spp = 1; ra.n_parts = 1; ra.tile_rows = 8;
+    ra.width_f = ra.height_f = 8.0f; ra.spp_f = 1.0f;
+    ra.tile_counter = words; ra.n_abandoned = words + 1; ra.abandoned = words + 48;
+    ra.order = words + 44; ra.split_tiles = words + 44; ra.n_split = words + 40;
+    ra.tile_cost = words + 45; ra.cost_sum = cost_sum;
+    RenderArgs seg = ra;
+    seg.seg_slots = words + 32; seg.seg = 0; seg.tile_counter = words + 8;
+    RenderArgs split = ra;
+    split.n_split = words + 41;
+    unsigned long long* const counters = cost_sum;        // non-null selects the counting variants; nothing is added
+    k_render<false, true, false, false><<<nb, 256, 0, s>>>(sc, ra);
+    k_render<false, true, false, true><<<nb, 256, 0, s>>>(sc, ra);
+    k_render_segment<false, true, false><<<nb, 256, 0, s>>>(sc, seg);
+    k_render_split<false, true, false><<<nb, 256, 0, s>>>(sc, split);
+    ra.counters = seg.counters = split.counters = counters;
+    k_render<true, true, false, false><<<nb, 256, 0, s>>>(sc, ra);
+    k_render<true, true, false, true><<<nb, 256, 0, s>>>(sc, ra);
+    k_render_segment<true, true, false><<<nb, 256, 0, s>>>(sc, seg);
+    k_render_split<true, true, false><<<nb, 256, 0, s>>>(sc, split);
+    // the tile-order kernels, on a one-tile frame (arrays inside the same 64 words)
+    e = launch_order_build(words + 45, 1u, cost_sum, 256, true, words + 50, words + 44, words + 46, words + 47, s);
+    if (e != hipSuccess) return e;
+    const uint32_t rows[3] = { 0u, 0u, 1u };
+    e = launch_order_segments(words + 44, words + 50, 1u, 1u, 1u, rows, 2, words + 32, s);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(words, 0, 64 * sizeof(uint32_t), s);
+}
+
+hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
+                              bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
                               uint32_t* wants_split, hipStream_t s) {
     const unsigned blocks = (n_tiles + 255u) / 256u;
     const uint32_t slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
