@@ -17,6 +17,11 @@ namespace hvrt {
 namespace {
 
 constexpr float EPS = FLT_EPSILON;   // GeometryUtils.cpp:64
+#if defined(HVRT_DIAG) && (HVRT_DIAG == 33 || HVRT_DIAG == 34)
+constexpr bool HVRT_DIAG_NO_SPLIT_COUNTS = true;
+#else
+constexpr bool HVRT_DIAG_NO_SPLIT_COUNTS = false;
+#endif
 #ifdef HVRT_DIAG
 constexpr bool HVRT_DIAG_BUILD = true;
 #else
@@ -811,12 +816,16 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
 // resident wave fills issue slots -- 5 / 6 / 7 / 8 waves: 91.4 / 81.8 / 78.4 / 73.6 ms on config 4.  The plain kernel
 // fits in 63 registers with no scratch (scripts/kernel_resources.sh) since the camera frame stopped living in twelve
 // vector registers across the walk (render_pixel); the counting variants keep 24-40 bytes per lane there.
-template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 #ifndef HVRT_RENDER_WAVES
 #define HVRT_RENDER_WAVES 8
 #endif
+#ifndef HVRT_RENDER_BLOCK
+#define HVRT_RENDER_BLOCK 256          // lanes per workgroup of k_render / k_render_segment
+#endif
+constexpr uint32_t RENDER_BLOCK_WAVES = HVRT_RENDER_BLOCK / 64;
+template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArgs& ra) {
-    __shared__ float4 lds_win[4][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
+    __shared__ float4 lds_win[RENDER_BLOCK_WAVES][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
     // (the lane number is worked out where it is needed, lane_now(): a register held for it would be spilled)
     float4* const win = lds_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
@@ -828,6 +837,15 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     const uint32_t slot0 = ra.seg_slots ? ra.seg_slots[ra.seg] : 0u;
     const uint32_t n_queue = ra.seg_slots ? ra.seg_slots[ra.seg + 1] : (ra.order ? n_tiles - *ra.n_split : n_tiles);
     uint64_t tot_nv = 0, tot_nt = 0;
+#if defined(HVRT_DIAG) && HVRT_DIAG == 32       // a wave's lifetime in the kernel | the clocks it spent inside tiles (16-clock units x 16)
+    const long long life0 = clock64();
+#endif
+#if defined(HVRT_DIAG) && (HVRT_DIAG >= 34 && HVRT_DIAG <= 39)   // 35: the hit count becomes the sum of the waves' lifetimes (10-ns ticks), any variant; 36: of their start delays behind workgroup 0
+    const unsigned long long life_wall0 = wall_clock64();
+#if HVRT_DIAG >= 36
+    if (blockIdx.x == 0 && threadIdx.x == 0) ra.abandoned[0] = (uint32_t)life_wall0;
+#endif
+#endif
     uint32_t tot_hits = 0;                // wave-uniform
     unsigned long long wave_cost = 0;     // wave-uniform
     uint32_t given_up = 0xFFFFFFFFu;      // wave-uniform: the tile the previous iteration gave up on (see below)
@@ -843,7 +861,11 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     constexpr uint32_t MAX_BATCH = 8;
     uint32_t batch = 1, slot = 0, slot_end = 0;     // wave-uniform
     long long batch_clk0 = 0;
-    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t n_waves = gridDim.x * RENDER_BLOCK_WAVES;
+    // A wave's FIRST slot is its own number: 8192 waves asking the head for one slot each at the same moment is 93 us
+    // of the word's atomic rate, 46 us of waiting for the mean wave, in a 1.7-ms launch.  The head hands out what lies
+    // behind those first n_waves slots.
+    bool first_pull = true;
 
     for (;;) {
         if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
@@ -853,8 +875,14 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31       // clocks spent waiting for the queue head | clocks in the loop, per wave
             const long long pull0 = clock64();
 #endif
-            if (lane_now() == 0) got = atomicAdd(ra.tile_counter, batch);
-            slot = slot0 + (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
+            if (first_pull) {
+                got = blockIdx.x * RENDER_BLOCK_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                first_pull = false;
+            } else {
+                if (lane_now() == 0) got = atomicAdd(ra.tile_counter, batch);
+                got = n_waves + (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
+            }
+            slot = slot0 + got;
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31
             if (COUNT && lane_now() == 0) { tot_nv += (uint64_t)(clock64() - pull0); tot_nt += 1; }
 #endif
@@ -925,7 +953,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #endif
             wave_cost += dc;
             if (dropped) given_up = tile;                       // appended to the list by the next iteration
-#if !defined(HVRT_DIAG) || HVRT_DIAG != 31
+#if !defined(HVRT_DIAG) || (HVRT_DIAG != 31 && HVRT_DIAG != 32 && HVRT_DIAG != 33 && HVRT_DIAG != 34)
             else if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
 #endif
             if (ra.hits && !dropped) tot_hits += (uint32_t)__builtin_popcountll(any_lane(inside && px.hit != HVRT_MISS));
@@ -940,9 +968,37 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
         }
     }
     if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
+#if defined(HVRT_DIAG) && HVRT_DIAG == 32
+    if (COUNT) { tot_nv = lane_now() == 0 ? (uint64_t)(clock64() - life0) : 0ull; tot_nt = lane_now() == 0 ? (uint64_t)wave_cost << 4 : 0ull; }
+#endif
+#if defined(HVRT_DIAG) && (HVRT_DIAG == 33 || HVRT_DIAG == 34)   // 33: sum | max of the waves' end times, 34: of their start times (100 MHz wall clock)
+    if (COUNT && ra.counters) {
+        if (lane_now() == 0) {
+#if HVRT_DIAG == 33
+            const unsigned long long tw = wall_clock64();
+#else
+            const unsigned long long tw = life_wall0;
+#endif
+            atomicAdd(&ra.counters[0], tw & 0xFFFFFFFFull);
+            atomicMax(&ra.counters[1], HVRT_DIAG == 33 ? (tw & 0xFFFFFFFFull) : (0xFFFFFFFFull - (tw & 0xFFFFFFFFull)));
+        }
+        tot_nv = tot_nt = 0;
+    }
+#endif
     const int lane = lane_now();
     if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
+#if defined(HVRT_DIAG) && HVRT_DIAG == 35
+    if (lane == 0 && ra.hits) atomicAdd(ra.hits, wall_clock64() - life_wall0);
+#elif defined(HVRT_DIAG) && HVRT_DIAG >= 36 && HVRT_DIAG <= 39    // sum / max of start delays (36 / 37), sum / max of end times (38 / 39), behind workgroup 0's start
+    if (lane == 0 && ra.hits) {
+        const uint32_t tw = HVRT_DIAG <= 37 ? (uint32_t)life_wall0 : (uint32_t)wall_clock64();
+        const int d = (int)(tw - ra.abandoned[0]);
+        const unsigned long long v = (unsigned long long)(d > 0 ? d : 0);
+        if (HVRT_DIAG == 36 || HVRT_DIAG == 38) atomicAdd(ra.hits, v); else atomicMax(ra.hits, v);
+    }
+#else
     if (lane == 0 && tot_hits) atomicAdd(ra.hits, (unsigned long long)tot_hits);
+#endif
     if (COUNT && ra.counters) {
         tot_nv = wave_sum64(tot_nv);
         tot_nt = wave_sum64(tot_nt);
@@ -954,14 +1010,14 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 }
 
 template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render(SceneDev sc, RenderArgs ra) {
+__global__ __launch_bounds__(HVRT_RENDER_BLOCK) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render(SceneDev sc, RenderArgs ra) {
     render_tiles<COUNT, INLINE, NEAREST, ABORT>(sc, ra);
 }
 // The same code under a second name, for launches over a range of the queue's slots (RenderArgs::seg_slots, the host
 // path's half frames): a kernel trace then lists whole-frame launches and part launches separately instead of
 // averaging them into one row.
 template <bool COUNT, bool INLINE, bool NEAREST>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render_segment(SceneDev sc, RenderArgs ra) {
+__global__ __launch_bounds__(HVRT_RENDER_BLOCK) __attribute__((amdgpu_waves_per_eu(HVRT_RENDER_WAVES, HVRT_RENDER_WAVES))) void k_render_segment(SceneDev sc, RenderArgs ra) {
     render_tiles<COUNT, INLINE, NEAREST, false>(sc, ra);
 }
 
@@ -1011,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
         wave_cost += dc;
     }
     if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
-    if (COUNT && ra.counters) {
+    if (COUNT && ra.counters && !(HVRT_DIAG_BUILD && HVRT_DIAG_NO_SPLIT_COUNTS)) {
         tot_nv = wave_sum64(tot_nv);
         tot_nt = wave_sum64(tot_nt);
         if (lane == 0 && (tot_nv | tot_nt)) {
@@ -1215,14 +1271,14 @@ uint64_t render_tile_count(int width, int local_rows, int n_frames) {
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s) {
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0) return hipSuccess;
-    uint64_t blocks = (n_tiles + 3) / 4;
-    const uint64_t cap = (uint64_t)n_cus * 8;   // 8 x 256-thread workgroups fill a CU's 32 wave slots
+    uint64_t blocks = (n_tiles + RENDER_BLOCK_WAVES - 1) / RENDER_BLOCK_WAVES;
+    const uint64_t cap = (uint64_t)n_cus * 4u * HVRT_RENDER_WAVES / RENDER_BLOCK_WAVES;   // workgroups that fill the CUs' wave slots
     if (blocks > cap) blocks = cap;
     const bool il = sc.ref_rec != nullptr;
     const unsigned nb = (unsigned)blocks;
-#define HVRT_LAUNCH3(C, I, N) do { if (abortable) k_render<C, I, N, true><<<nb, 256, 0, s>>>(sc, ra); \
-                                   else if (ra.seg_slots) k_render_segment<C, I, N><<<nb, 256, 0, s>>>(sc, ra); \
-                                   else k_render<C, I, N, false><<<nb, 256, 0, s>>>(sc, ra); } while (0)
+#define HVRT_LAUNCH3(C, I, N) do { if (abortable) k_render<C, I, N, true><<<nb, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra); \
+                                   else if (ra.seg_slots) k_render_segment<C, I, N><<<nb, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra); \
+                                   else k_render<C, I, N, false><<<nb, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra); } while (0)
 #define HVRT_LAUNCH(C, I) do { if (ra.nearest) HVRT_LAUNCH3(C, I, true); else HVRT_LAUNCH3(C, I, false); } while (0)
     if (ra.counters) { if (il) HVRT_LAUNCH(true, true); else HVRT_LAUNCH(true, false); }
     else             { if (il) HVRT_LAUNCH(false, true); else HVRT_LAUNCH(false, false); }
@@ -1281,14 +1337,14 @@ hipError_t launch_render_warmup(uint32_t* words, unsigned long long* cost_sum, i
     RenderArgs split = ra;
     split.n_split = words + 41;
     unsigned long long* const counters = cost_sum;        // non-null selects the counting variants; nothing is added
-    k_render<false, true, false, false><<<nb, 256, 0, s>>>(sc, ra);
-    k_render<false, true, false, true><<<nb, 256, 0, s>>>(sc, ra);
-    k_render_segment<false, true, false><<<nb, 256, 0, s>>>(sc, seg);
+    k_render<false, true, false, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
+    k_render<false, true, false, true><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
+    k_render_segment<false, true, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, seg);
     k_render_split<false, true, false><<<nb, 256, 0, s>>>(sc, split);
     ra.counters = seg.counters = split.counters = counters;
-    k_render<true, true, false, false><<<nb, 256, 0, s>>>(sc, ra);
-    k_render<true, true, false, true><<<nb, 256, 0, s>>>(sc, ra);
-    k_render_segment<true, true, false><<<nb, 256, 0, s>>>(sc, seg);
+    k_render<true, true, false, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
+    k_render<true, true, false, true><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
+    k_render_segment<true, true, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, seg);
     k_render_split<true, true, false><<<nb, 256, 0, s>>>(sc, split);
     // the tile-order kernels, on a one-tile frame (arrays inside the same 64 words)
     e = launch_order_build(words + 45, 1u, cost_sum, 256, true, words + 50, words + 44, words + 46, words + 47, s);
