@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -457,23 +458,38 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipMalloc((void**)&c->bounds_v, 2048 * 6 * sizeof(float))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_i, 2048 * 6 * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->bounds_out, 256)) != hipSuccess) return bail("hipMalloc", e);
-    // The reference constructs a tracer per image and renders once (TraceImages.cpp:215-229): what the process pays once
-    // for a traversal kernel's first dispatch is paid here, not inside that one render() (HVRT_WARMUP=0: not at all).
+    // The reference constructs a tracer per image and renders once (TraceImages.cpp:215-229): what a process pays once
+    // per hardware queue -- its scratch memory, the first pass through the download ring -- is paid here, not inside
+    // that one render() (HVRT_WARMUP=0: not at all).
     const char* warm = getenv("HVRT_WARMUP");
     if (!warm || atoi(warm) != 0) {
         if ((e = hipMemsetAsync(c->tile_counter, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         if ((e = hipMemsetAsync(c->cost_sum, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
-        if ((e = launch_render_warmup(c->tile_counter, c->cost_sum, c->n_cus, c->stream)) != hipSuccess) return bail("warm-up launches", e);
-        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
-        // and one pass through the download ring on each of the two streams a frame comes back on
+        // the download ring on the copy stream WHILE the main stream is busy with the launches -- that is how a frame
+        // comes back (hvrt_render's two-launch path), and streams that are busy at the same time for the first time cost
+        // the process a hardware queue's set-up -- then once on the main stream
         const size_t wb = 4 * hvrt_ctx::PIN_CHUNK;
         void* d_tmp = nullptr;
         std::vector<char> h_tmp(wb);
         if ((e = hipMalloc(&d_tmp, wb)) != hipSuccess) return bail("hipMalloc", e);
-        int rc = download(c, h_tmp.data(), d_tmp, wb, c->stream);
-        if (rc == HVRT_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = HVRT_ERR_HIP;
-        if (rc == HVRT_OK) rc = download(c, h_tmp.data(), d_tmp, wb, c->copy_stream);
+        if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return bail("hipStreamSynchronize", e);
+        e = launch_scratch_warmup(c->tile_counter, c->n_cus, c->stream);
+        if (e != hipSuccess) { (void)hipFree(d_tmp); return bail("warm-up launches", e); }
+        // (the two other streams -- k_render_split beside k_render, the distance field beside the fill -- each with work
+        // of its own in flight at the same time)
+        // -- and the scratch of the second stream's queue)
+        e = launch_scratch_warmup((uint32_t*)d_tmp, c->n_cus, c->aux_stream);
+        if (e != hipSuccess) { (void)hipFree(d_tmp); return bail("warm-up launches", e); }
+        (void)hipMemsetAsync((char*)c->counters + 192, 0, 64, c->df_stream);
+        // (the copy stream waits for an event of the main stream first, as it does for a half frame)
+        (void)hipEventRecord(c->ev_seg[0], c->stream);
+        (void)hipStreamWaitEvent(c->copy_stream, c->ev_seg[0], 0);
+        int rc = download(c, h_tmp.data(), d_tmp, wb, c->copy_stream);
         if (rc == HVRT_OK && hipStreamSynchronize(c->copy_stream) != hipSuccess) rc = HVRT_ERR_HIP;
+        if (rc == HVRT_OK && (hipStreamSynchronize(c->aux_stream) != hipSuccess || hipStreamSynchronize(c->df_stream) != hipSuccess)) rc = HVRT_ERR_HIP;
+        if (rc == HVRT_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = HVRT_ERR_HIP;
+        if (rc == HVRT_OK) rc = download(c, h_tmp.data(), d_tmp, wb, c->stream);
+        if (rc == HVRT_OK && hipStreamSynchronize(c->stream) != hipSuccess) rc = HVRT_ERR_HIP;
         (void)hipFree(d_tmp);
         if (rc != HVRT_OK) { g_create_error = "warm-up of the download ring failed: " + c->error; hvrt_destroy(c); return rc; }
     }
@@ -953,17 +969,20 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     if (n_tiles > 0x7FFFFFFFull) return fail(c, HVRT_ERR_INVALID, "render: too many tiles in one launch");
     hipStream_t s = c->stream;
 
-    // camera frames -> device (pinned staging, so the copy is asynchronous; a slot is reused only after the
-    // copy that last used it has run)
-    const int slot = c->cam_next;
-    c->cam_next = (c->cam_next + 1) % hvrt_ctx::CAM_SLOTS;
-    if (c->cam_ev_used[slot]) HIP_TRY(c, hipEventSynchronize(c->cam_ev[slot]));
-    hvrt_camera_frame* hs = c->cam_host + (size_t)slot * hvrt_ctx::CAM_MAX;
-    hvrt_camera_frame* ds = c->cam_dev + (size_t)slot * hvrt_ctx::CAM_MAX;
-    memcpy(hs, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames);
-    HIP_TRY(c, hipMemcpyAsync(ds, hs, sizeof(hvrt_camera_frame) * (size_t)n_frames, hipMemcpyHostToDevice, s));
-    HIP_TRY(c, hipEventRecord(c->cam_ev[slot], s));
-    c->cam_ev_used[slot] = true;
+    // camera frames: a single one travels inside the kernel arguments; a batch goes to the device through pinned
+    // staging (so the copy is asynchronous; a slot is reused only after the copy that last used it has run)
+    hvrt_camera_frame* ds = nullptr;
+    if (n_frames > 1) {
+        const int slot = c->cam_next;
+        c->cam_next = (c->cam_next + 1) % hvrt_ctx::CAM_SLOTS;
+        if (c->cam_ev_used[slot]) HIP_TRY(c, hipEventSynchronize(c->cam_ev[slot]));
+        hvrt_camera_frame* hs = c->cam_host + (size_t)slot * hvrt_ctx::CAM_MAX;
+        ds = c->cam_dev + (size_t)slot * hvrt_ctx::CAM_MAX;
+        memcpy(hs, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames);
+        HIP_TRY(c, hipMemcpyAsync(ds, hs, sizeof(hvrt_camera_frame) * (size_t)n_frames, hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipEventRecord(c->cam_ev[slot], s));
+        c->cam_ev_used[slot] = true;
+    }
 
     // tile order: longest first, from the previous launch of the same shape
     const int key[8] = { width, height, tile_rows, part, n_parts, n_frames, spp, 1 };
@@ -978,7 +997,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     c->order_ahead = false;
 
     RenderArgs ra;
-    ra.frames = ds; ra.n_frames = n_frames;
+    ra.frames = ds; ra.frame0 = frames[0]; ra.n_frames = n_frames;
     ra.width = width; ra.height = height; ra.spp = spp; ra.seed = seed;
     ra.width_f = (float)width; ra.height_f = (float)height; ra.spp_f = (float)spp;
     ra.nearest = c->mode;
@@ -1049,14 +1068,18 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     // clean queue head / cost sum that launch starts from
     if (c->adaptive_order && n_tiles) {
         const bool may_split = c->adaptive_split && *(volatile uint32_t*)c->split_hint != 0u;
+        // (its last kernel also clears the queue heads and the next launch's cost sum: two memsets fewer in the stream)
         HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, ra.cost_sum, c->n_cus, may_split, c->order_blocks,
-                                      c->tile_order, c->split_tiles, c->split_hint_dev, s));
+                                      c->tile_order, c->split_tiles, c->split_hint_dev, c->tile_counter,
+                                      c->cost_sum + (c->cost_parity ^ 1), s));
         c->order_ahead = true;
         c->order_may_split = may_split;
+        c->cost_parity ^= 1;
+    } else {
+        c->cost_parity ^= 1;
+        HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity, 0, sizeof(unsigned long long), s));
     }
-    c->cost_parity ^= 1;
-    HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));
-    HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity, 0, sizeof(unsigned long long), s));
     c->queue_clean = true;
     memcpy(c->cost_key, key, sizeof key);
     c->cost_valid = true;
@@ -1165,12 +1188,19 @@ int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int heig
     // rest): the first half crosses PCIe while the second is traced.  Needs the tile history (a first launch of a
     // shape is one launch, copied afterwards).
     SegPlan plan;
+    static const bool trace_times = getenv("HVRT_TRACE_TIMES") != nullptr;      // diagnostics: host time stamps of this call
+    const auto t_start = std::chrono::steady_clock::now();
+    auto stamp = [&](const char* what) {
+        if (trace_times) fprintf(stderr, "[hvrt_render] %-28s %8.3f ms\n", what,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
+    };
     const uint32_t tiles_y = (uint32_t)(height + 7) >> 3;
     // (only when the colours alone are wanted: with three arrays to fetch the copies are the longer part either way)
     if (npx >= (1u << 21) && tiles_y >= 16 && !hit_id && !t) { plan.n = 2; plan.row[0] = 0; plan.row[1] = tiles_y / 2; plan.row[2] = tiles_y; }
     if (int r = render_batch_part(c, frame, 1, width, height, spp, seed, height, 0, 1, height,
                                   rgb ? c->out_buf[0] : nullptr, hit_id ? c->out_buf[1] : nullptr,
                                   t ? c->out_buf[2] : nullptr, counters ? c->counters : nullptr, c->counters + 2, &plan)) return r;
+    stamp("launches queued");
     uint64_t h_cnt[3] = { 0, 0, 0 };
     if (plan.used) {
         for (int b = 0; b < plan.n; ++b) {
@@ -1180,6 +1210,7 @@ int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int heig
             if (rgb) if (int r = download(c, rgb + 3 * p0, (const char*)c->out_buf[0] + 12 * p0, np * 12, c->copy_stream)) return r;
             if (hit_id) if (int r = download(c, hit_id + p0, (const char*)c->out_buf[1] + 4 * p0, np * 4, c->copy_stream)) return r;
             if (t) if (int r = download(c, t + p0, (const char*)c->out_buf[2] + 4 * p0, np * 4, c->copy_stream)) return r;
+            stamp("segment downloaded");
         }
         HIP_TRY(c, hipMemcpyAsync(h_cnt, c->counters, sizeof h_cnt, hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(c->copy_stream));
@@ -1190,6 +1221,7 @@ int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int heig
         if (t) if (int r = download(c, t, c->out_buf[2], npx * 4, s)) return r;
     }
     HIP_TRY(c, hipStreamSynchronize(s));
+    stamp("synchronised");
     if (counters) { counters[0] = h_cnt[0]; counters[1] = h_cnt[1]; }
     c->last_hits = h_cnt[2];
     c->tm.render_ms = ms_between(c->ev[6], c->ev[7]);

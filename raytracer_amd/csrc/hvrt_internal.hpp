@@ -47,7 +47,8 @@ struct SceneDev {
 };
 
 struct RenderArgs {
-    const hvrt_camera_frame* frames;   // n_frames camera frames, DEVICE memory (read with scalar loads)
+    const hvrt_camera_frame* frames;   // n_frames camera frames, DEVICE memory (read with scalar loads); null: the one frame below
+    hvrt_camera_frame frame0;          // a single frame travels as a kernel argument (no copy in front of the launch)
     int n_frames;
     int width, height;       // full frame
     int spp;
@@ -141,8 +142,8 @@ hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* 
 int bounds_blocks(uint64_t n_points);
 
 // ---- launchers (hvrt_trace.hip) ----
-// empty launches of the traversal kernels (code resolution, scratch set-up); words: 64 zeroed u32, left zeroed
-hipError_t launch_render_warmup(uint32_t* words, unsigned long long* cost_sum, int n_cus, hipStream_t s);
+// a full-size dispatch of a kernel with 160 bytes of scratch per lane (a queue's scratch set-up), nothing else
+hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s);
 // abortable: the kernel may give up on over-long tiles (ra.abandoned); a launch_render_split over that list must follow
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
@@ -153,7 +154,8 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
 // (device-visible host memory) <- the number of tiles that qualify for splitting, whatever may_split says.
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
-                              uint32_t* wants_split, hipStream_t s);
+                              uint32_t* wants_split, uint32_t* clear_heads /* 16 words, nullable */,
+                              unsigned long long* clear_sum /* nullable */, hipStream_t s);
 // seg_slots[0..n_seg] <- the slot ranges of n_seg launches over the queue launch_order_build left: launch b covers the
 // tiles of tile rows [row_bounds[b], row_bounds[b + 1]) that are in k_render's queue behind the long ones; launch 0
 // also takes the long tiles, which sit at the queue's head (row_bounds[0] = 0, row_bounds[n_seg] = tile rows; n_seg <= 8)

@@ -767,7 +767,12 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
     const uint64_t cf_bits = (uint64_t)(uintptr_t)cf;       // the same for every lane: say so
     const uint64_t cf_uniform = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)cf_bits) |
                                 ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(cf_bits >> 32)) << 32);
-    const_floats cfs = (const_floats)cf_uniform;
+    // (ra.frames == nullptr: the launch's single frame is RenderArgs::frame0, i.e. it lies in the kernel-argument segment --
+    // every kernel that gets here has the parameter list (SceneDev, RenderArgs) -- and is read from there the same way)
+    typedef const __attribute__((address_space(4))) char* const_bytes;
+    constexpr size_t RA_IN_KERNARG = (sizeof(SceneDev) + alignof(RenderArgs) - 1) / alignof(RenderArgs) * alignof(RenderArgs);
+    const_floats cfs = ra.frames ? (const_floats)cf_uniform
+                          : (const_floats)((const_bytes)__builtin_amdgcn_kernarg_segment_ptr() + RA_IN_KERNARG + offsetof(RenderArgs, frame0));
     V3 org = { cfs[0], cfs[1], cfs[2] };
     // (the origin is an operand of every ray / triangle test: in vector registers, where the walk can use it without a
     // second scalar operand in one instruction)
@@ -930,7 +935,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #if defined(HVRT_ABLATE) && HVRT_ABLATE >= 6
             px.rgb = { 0.5f, 0.5f, (float)x }; px.hit = HVRT_MISS; px.t = FLT_MAX;
 #else
-            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, tx, ty, -1, 0, 0, inside, win, wall0, px);
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, inside, win, wall0, px);
 #endif
 #if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)
             int x2, lr2, y2;
@@ -938,7 +943,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
             if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr2, x2, px);
 #endif
         } else if (inside) {
-            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames + fi, tx, ty, -1, 0, 0, true, nullptr, wall0, px);
+            gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, true, nullptr, wall0, px);
             // the wave decides; a lane that finished its pixel holds its stores back until then
             if (!ABORT || any_lane(gave_up) == 0ull) store_pixel(ra, fi, lr, x, px);
         }
@@ -1051,7 +1056,7 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
         const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
             PixelResult px;
-            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames + fi, 0u, 0u, lane, x, y, true, nullptr, wall0, px);
+            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames ? ra.frames + fi : nullptr, 0u, 0u, lane, x, y, true, nullptr, wall0, px);
             if (slice == 0) {
                 store_pixel(ra, fi, lr, x, px);
                 if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
@@ -1143,7 +1148,11 @@ __global__ __launch_bounds__(1024) void k_order_scan(uint32_t* __restrict__ bloc
 __global__ __launch_bounds__(256) void k_order_place(uint32_t* __restrict__ cost, uint32_t n,
                                                      const unsigned long long* __restrict__ sum, uint32_t slots, bool may_split,
                                                      const uint32_t* __restrict__ block_count, uint32_t n_blocks,
-                                                     uint32_t* __restrict__ order, uint32_t* __restrict__ split_tiles) {
+                                                     uint32_t* __restrict__ order, uint32_t* __restrict__ split_tiles,
+                                                     uint32_t* __restrict__ clear_heads, unsigned long long* __restrict__ clear_sum) {
+    // (nullable: the sixteen queue-head words and the cost sum the NEXT launch starts from -- not the sum read here)
+    if (blockIdx.x == 0 && threadIdx.x < 16 && clear_heads) clear_heads[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 16 && clear_sum) *clear_sum = 0ull;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const int cls = i < n ? tile_class(cost[i], *sum, n, slots, may_split) : 0;
     __shared__ uint32_t w[2][4];
@@ -1307,63 +1316,33 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
     return hipGetLastError();
 }
 
-hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
-                              bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
-                              uint32_t* wants_split, hipStream_t s);
-hipError_t launch_order_segments(const uint32_t* order, const uint32_t* block_count, uint32_t n_blocks, uint32_t n_tiles,
-                                 uint32_t tiles_x, const uint32_t* row_bounds, int n_seg, uint32_t* seg_slots, hipStream_t s);
-
-// One empty launch of every traversal kernel a first frame can need (reference traversal, per-reference records; with
-// and without the statistics): the runtime resolves a kernel's code and sets up the scratch its private segment needs
-// when it is first dispatched, which cost the first hvrt_render of a process 6 ms of its 11.5 (and the second, which
-// runs other variants, another 5) -- paid in hvrt_create instead, where the runtime's own start-up is 30 times that.
-// words: 64 zeroed device words; the launches find an empty queue (words[40] = 1 tile, all of it "split away";
-// words[41] = 0 tiles for k_render_split; the segment's slot range words[32..33] is empty) and end at once.
-hipError_t launch_render_warmup(uint32_t* words, unsigned long long* cost_sum, int n_cus, hipStream_t s) {
-    // (full-size grids: the runtime sizes a queue's scratch by the waves of the dispatch that needs it)
+// Warm-up of a hardware queue (hvrt_create): the runtime gives a queue its scratch memory when a dispatch first needs
+// some, and again when a later dispatch needs more -- 4 to 5 ms each time, which the first render() of a process paid
+// for its counting kernel and the second for the variant it runs.  One full-size dispatch of a kernel that needs more
+// scratch per lane than any traversal kernel (176 bytes against at most 116) settles that per queue, and no k_render
+// launch of a profiled run is an empty one.  (Launching the traversal kernels themselves empty brought nothing more.)
+__global__ __launch_bounds__(256) void k_warm_scratch(uint32_t* sink, uint32_t n) {
+    volatile uint32_t spill[40];
+    for (uint32_t i = 0; i < 40; ++i) spill[i] = i * n + threadIdx.x;
+    uint32_t acc = 0;
+    for (uint32_t i = 0; i < 40; ++i) acc += spill[(i * 7u + n) % 40u];
+    if (n == 0xFFFFFFFFu) sink[0] = acc;        // never: n is the grid size
+}
+hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s) {
     const unsigned nb = (unsigned)n_cus * 8u;
-    const uint32_t one = 1u;
-    hipError_t e = hipMemcpyAsync(words + 40, &one, sizeof one, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
-    SceneDev sc = {};
-    RenderArgs ra = {};
-    ra.n_frames = 1; ra.width = 8; ra.height = 8; ra.local_rows = 8; ra.slab_rows = 8; ra.spp = 1; ra.n_parts = 1; ra.tile_rows = 8;
-    ra.width_f = ra.height_f = 8.0f; ra.spp_f = 1.0f;
-    ra.tile_counter = words; ra.n_abandoned = words + 1; ra.abandoned = words + 48;
-    ra.order = words + 44; ra.split_tiles = words + 44; ra.n_split = words + 40;
-    ra.tile_cost = words + 45; ra.cost_sum = cost_sum;
-    RenderArgs seg = ra;
-    seg.seg_slots = words + 32; seg.seg = 0; seg.tile_counter = words + 8;
-    RenderArgs split = ra;
-    split.n_split = words + 41;
-    unsigned long long* const counters = cost_sum;        // non-null selects the counting variants; nothing is added
-    k_render<false, true, false, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
-    k_render<false, true, false, true><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
-    k_render_segment<false, true, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, seg);
-    k_render_split<false, true, false><<<nb, 256, 0, s>>>(sc, split);
-    ra.counters = seg.counters = split.counters = counters;
-    k_render<true, true, false, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
-    k_render<true, true, false, true><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, ra);
-    k_render_segment<true, true, false><<<nb * 4u / RENDER_BLOCK_WAVES, HVRT_RENDER_BLOCK, 0, s>>>(sc, seg);
-    k_render_split<true, true, false><<<nb, 256, 0, s>>>(sc, split);
-    // the tile-order kernels, on a one-tile frame (arrays inside the same 64 words)
-    e = launch_order_build(words + 45, 1u, cost_sum, 256, true, words + 50, words + 44, words + 46, words + 47, s);
-    if (e != hipSuccess) return e;
-    const uint32_t rows[3] = { 0u, 0u, 1u };
-    e = launch_order_segments(words + 44, words + 50, 1u, 1u, 1u, rows, 2, words + 32, s);
-    if (e != hipSuccess) return e;
-    return hipMemsetAsync(words, 0, 64 * sizeof(uint32_t), s);
+    k_warm_scratch<<<nb, 256, 0, s>>>(sink, nb);
+    return hipGetLastError();
 }
 
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
-                              uint32_t* wants_split, hipStream_t s) {
+                              uint32_t* wants_split, uint32_t* clear_heads, unsigned long long* clear_sum, hipStream_t s) {
     const unsigned blocks = (n_tiles + 255u) / 256u;
     const uint32_t slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
     may_split = may_split && n_tiles <= 0x0FFFFFFFu;       // 16 items per tile in a 32-bit count
     k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count);
     k_order_scan<<<2, 1024, 0, s>>>(block_count, blocks, may_split, wants_split);
-    k_order_place<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count, blocks, order, split_tiles);
+    k_order_place<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count, blocks, order, split_tiles, clear_heads, clear_sum);
     return hipGetLastError();
 }
 

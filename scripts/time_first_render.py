@@ -22,10 +22,11 @@ for k in range(2):
     ctx.build_grid(g, g, g, mn, mx, vs)
     t2 = time.perf_counter()
     cam = capi.make_camera_frame(*capi.default_camera(mn, mx, "front", aspect=W / H))
-    ts = []
+    ts, ks = [], []
     for i in range(5):
         a = time.perf_counter()
         assert lib.hvrt_render(ctx._h, C.byref(cam), W, H, 1, 0, p(rgb), None, None, p(cnt)) == 0
         ts.append((time.perf_counter() - a) * 1e3)
-    print(f"context {k}: create {1e3*(t1-t0):.1f} ms, mesh + grid {1e3*(t2-t1):.1f} ms, first render {ts[0]:.2f} ms, second {ts[1]:.2f}, best {min(ts[1:]):.2f}", flush=True)
+        ks.append(ctx.timings().render_ms)
+    print(f"context {k}: create {1e3*(t1-t0):.1f} ms, mesh + grid {1e3*(t2-t1):.1f} ms, first render {ts[0]:.2f} ms, second {ts[1]:.2f}, best {min(ts[1:]):.2f}; traversal by events: " + " ".join(f"{k:.2f}" for k in ks), flush=True)
     ctx.close()
