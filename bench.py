@@ -130,6 +130,44 @@ def render_roofline(prof, k_ms, rays, bytes_per_ray):
     return out
 
 
+def rehearse_on_one_gpu(dist, D, torch):
+    """HVRT_BENCH_REHEARSE=1: every rank uses GPU 0 and the collectives travel over gloo, staged through host memory
+    (RCCL cannot put two ranks on one device).  For checking, on a one-GPU machine, that the N > 1 code of this file
+    runs end to end (tests/test_gpu_distributed.py); the numbers of such a run mean nothing."""
+    real_broadcast, real_a2a, real_gather = dist.broadcast, dist.all_to_all_single, dist.all_gather_into_tensor
+
+    class Done:
+        def wait(self):
+            return True
+
+    def broadcast(t, src=0, group=None, async_op=False):
+        if not t.is_cuda:
+            return real_broadcast(t, src=src, group=group)
+        torch.cuda.synchronize()
+        h = t.cpu()
+        real_broadcast(h, src=src, group=group)
+        t.copy_(h)
+        torch.cuda.synchronize()
+
+    def all_to_all_single(out, inp, group=None, async_op=False):
+        torch.cuda.synchronize()
+        hi, ho = inp.cpu(), torch.empty(out.shape, dtype=out.dtype)
+        real_a2a(ho, hi, group=group)
+        out.copy_(ho)
+        torch.cuda.synchronize()
+        return Done()
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        torch.cuda.synchronize()
+        hi = inp.cpu().contiguous()
+        parts = [torch.empty_like(hi) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(parts, hi, group=group)
+        out.copy_(torch.stack(parts).reshape(out.shape))
+        torch.cuda.synchronize()
+
+    D.dist.broadcast, D.dist.all_to_all_single, D.dist.all_gather_into_tensor = broadcast, all_to_all_single, all_gather_into_tensor
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,6 +184,7 @@ def main():
     import torch.distributed as dist
     import raytracer_amd as ra
     from raytracer_amd import capi
+    from raytracer_amd import distributed as D
     from raytracer_amd.distributed import DistributedRenderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -155,12 +194,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    rehearse = os.environ.get("HVRT_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     rccl = {"world_size": 1, "backend": None}
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            rehearse_on_one_gpu(dist, D, torch)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         rccl = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
                 "exchange": "rgb8 slabs (3 B per pixel), " + ("all_to_all, frame f to rank f" if args.scaling == "weak" else "all_gather, every rank gets the frame")}
 
@@ -178,6 +224,8 @@ def main():
         ctx.synchronize()
 
     base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "vs_baseline": None, "dtype": "f32", "data": "synthetic", "rccl": rccl}
+    if rehearse:
+        base["rehearsal"] = "HVRT_BENCH_REHEARSE=1: all ranks on GPU 0, collectives over gloo through host memory -- the numbers mean nothing"
     scene = {"refs": int(info.n_refs), "occupied_voxels": int(info.n_occupied), "max_list": int(info.max_list)}
     nvox = g ** 3
     b_build = 72.0 * info.n_triangles + 12.0 * nvox + 20.0 * info.n_refs
@@ -345,7 +393,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
