@@ -129,6 +129,9 @@ __device__ __forceinline__ int dec_where(lanemask m, int v) {
 }
 // advanceToNextVoxel (:201-260) on explicit lane masks.  cxy picks the x-or-y candidate, c2 compares that candidate
 // with z: the nested ifs of :204-259 (ties and NaNs fall to the else arms exactly as written there).
+// (Tried: the step in assembly, each v_cmp followed at once by VOP2 selects on its fresh vcc -- 2 clocks each instead of
+// 4 -- and the masks copied out of vcc for the write-backs: 42 clocks of issue on paper instead of 52, but config 4 went
+// from 73.5 to 79.0 ms; the scalar copies of vcc wait for the vector pipeline twice per step.)
 #define HVRT_STEP()                                                             \
     do {                                                                        \
         const lanemask cxy = any_lane(tmx < tmy);                               \
@@ -845,13 +848,16 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #if defined(HVRT_DIAG) && HVRT_DIAG == 32       // a wave's lifetime in the kernel | the clocks it spent inside tiles (16-clock units x 16)
     const long long life0 = clock64();
 #endif
-#if defined(HVRT_DIAG) && (HVRT_DIAG >= 34 && HVRT_DIAG <= 39)   // 35: the hit count becomes the sum of the waves' lifetimes (10-ns ticks), any variant; 36: of their start delays behind workgroup 0
+#if defined(HVRT_DIAG) && (HVRT_DIAG >= 34 && HVRT_DIAG <= 41)   // 35: the hit count becomes the sum of the waves' lifetimes (10-ns ticks), any variant; 36: of their start delays behind workgroup 0
     const unsigned long long life_wall0 = wall_clock64();
 #if HVRT_DIAG >= 36
     if (blockIdx.x == 0 && threadIdx.x == 0) ra.abandoned[0] = (uint32_t)life_wall0;
 #endif
 #endif
     uint32_t tot_hits = 0;                // wave-uniform
+#if defined(HVRT_DIAG) && HVRT_DIAG == 41
+    uint32_t n_done = 0;
+#endif
     unsigned long long wave_cost = 0;     // wave-uniform
     uint32_t given_up = 0xFFFFFFFFu;      // wave-uniform: the tile the previous iteration gave up on (see below)
     // The queue head is ONE word, and one word takes about 88 returning atomics per microsecond from the whole chip
@@ -957,6 +963,9 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
             ra.tile_cost[tile] = dc;      // a dropped tile: k_render_split adds its quads' durations to this
 #endif
             wave_cost += dc;
+#if defined(HVRT_DIAG) && HVRT_DIAG == 41
+            ++n_done;
+#endif
             if (dropped) given_up = tile;                       // appended to the list by the next iteration
 #if !defined(HVRT_DIAG) || (HVRT_DIAG != 31 && HVRT_DIAG != 32 && HVRT_DIAG != 33 && HVRT_DIAG != 34)
             else if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
@@ -994,6 +1003,13 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
 #if defined(HVRT_DIAG) && HVRT_DIAG == 35
     if (lane == 0 && ra.hits) atomicAdd(ra.hits, wall_clock64() - life_wall0);
+#elif defined(HVRT_DIAG) && HVRT_DIAG == 40     // waves that started more than 0.5 ms behind workgroup 0 (and, << 32, more than 20 us)
+    if (lane == 0 && ra.hits) {
+        const int d = (int)((uint32_t)life_wall0 - ra.abandoned[0]);
+        atomicAdd(ra.hits, (unsigned long long)(d > 50000 ? 1 : 0) | ((unsigned long long)(d > 2000 ? 1 : 0) << 32));
+    }
+#elif defined(HVRT_DIAG) && HVRT_DIAG == 41     // tiles rendered by waves that started more than 0.5 ms late
+    if (lane == 0 && ra.hits) { const int d = (int)((uint32_t)life_wall0 - ra.abandoned[0]); atomicAdd(ra.hits, (unsigned long long)(d > 50000 ? n_done : 0u)); }
 #elif defined(HVRT_DIAG) && HVRT_DIAG >= 36 && HVRT_DIAG <= 39    // sum / max of start delays (36 / 37), sum / max of end times (38 / 39), behind workgroup 0's start
     if (lane == 0 && ra.hits) {
         const uint32_t tw = HVRT_DIAG <= 37 ? (uint32_t)life_wall0 : (uint32_t)wall_clock64();

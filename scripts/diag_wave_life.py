@@ -15,5 +15,7 @@ cam = capi.make_camera_frame(*capi.default_camera(mn, mx, "front", aspect=W / H)
 for i in range(4):
     ctx.render(cam, W, H, spp=spp, seed=1, want_hit=True, want_t=True, want_counters=False)
     ms = ctx.timings().render_ms
-    life = ctx.last_hit_count() / 8192 / 100.0
+    raw = ctx.last_hit_count()
+    life = raw / 8192 / 100.0
+    print(f'   raw counter {raw} (DIAG=40: low word = waves more than 0.5 ms late: {raw & 0xFFFFFFFF}, high word = more than 20 us late: {raw >> 32}; DIAG=41: tiles done by such waves)')
     print(f"launch {i}: render_ms {ms:.3f}, mean wave lifetime (DIAG=35; DIAG=36: mean start delay behind workgroup 0) {life:.1f} us -> {life/ms/10:.1f} % of the launch", flush=True)
