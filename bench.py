@@ -423,6 +423,17 @@ def main():
                            "frames_per_step": world if scaling == "weak" else 1, "tile_rows": 16,
                            "outputs": "rgb+hit_id+t" if world == 1 else "rgb, exchanged as 8-bit slabs"},
                    voxel_build_ms=build_ms, voxel_build_breakdown_ms=build_brk, scene=scene)
+        if world > 1:
+            # rank 0's last traversal launch (HIP events on libhvrt's stream): its row tiles of the step's frame(s).
+            # The busy fractions are the one-GPU profile's (same kernel, same scene); only kernel_ms and the rates are live.
+            k_ms = float(ctx.timings().render_ms)
+            rays0 = dr.part.rows_of(rank) * W * spp * (world if scaling == "weak" else 1)
+            prof = dict(load_profile(args.workload))
+            if prof.get("k_render_hbm_bytes_per_launch"):       # counted on a whole frame: this launch's share of it
+                prof["k_render_hbm_bytes_per_launch"] *= rays0 / float(W * H * spp)
+            out["roofline"] = dict(render_roofline(prof, k_ms, rays0, bytes_per_ray),
+                                   launch="rank 0's last launch of the timed region: %d rays (its row tiles of %s)"
+                                          % (rays0, "the batch's %d frames" % world if scaling == "weak" else "the frame"))
         if kernel_ms:
             k_ms = float(np.mean(kernel_ms))
             out["roofline"] = render_roofline(load_profile(args.workload), k_ms, W * H * spp, bytes_per_ray)
