@@ -263,11 +263,14 @@ int hvrt_group_replicate_scene(hvrt_group* g) {
         for (auto& a : arrays) {
             if (a.bytes == 0) continue;
             G_NCCL(g, g->rccl.GroupStart());
-            for (int i = 0; i < n; ++i) {
+            ncclResult_t first = ncclSuccess;         // (a group that was opened is closed whatever its calls returned)
+            for (int i = 0; i < n && first == ncclSuccess; ++i) {
                 void* recv = i == 0 ? const_cast<void*>(a.src) : (void*)(*a.dst)[i];       // in place on the root
-                G_NCCL(g, g->rccl.Broadcast(i == 0 ? a.src : recv, recv, a.bytes, ncclChar, 0, g->m[i].comm, g->m[i].stream));
+                first = g->rccl.Broadcast(i == 0 ? a.src : recv, recv, a.bytes, ncclChar, 0, g->m[i].comm, g->m[i].stream);
             }
-            G_NCCL(g, g->rccl.GroupEnd());
+            const ncclResult_t end = g->rccl.GroupEnd();
+            G_NCCL(g, first);
+            G_NCCL(g, end);
         }
         for (int i = 1; i < n; ++i) {
             G_HIP(g, hipSetDevice(g->m[i].device));
@@ -314,13 +317,16 @@ int hvrt_group_render(hvrt_group* g, const hvrt_camera_frame* frame, int width, 
         if (floats_of(0)) G_HIP(g, hipMemcpyAsync(g->parts, root.slab, floats_of(0) * 4, hipMemcpyDeviceToDevice, root.stream));
         if (g->transport == hvrt_group::RCCL) {
             G_NCCL(g, g->rccl.GroupStart());
-            for (int i = 1; i < n; ++i) {
+            ncclResult_t first = ncclSuccess;
+            for (int i = 1; i < n && first == ncclSuccess; ++i) {
                 if (!floats_of(i)) continue;
-                G_NCCL(g, g->rccl.Send(g->m[i].slab, floats_of(i), ncclFloat, 0, g->m[i].comm, g->m[i].stream));
-                G_NCCL(g, g->rccl.Recv(g->parts + slab_floats * i, floats_of(i), ncclFloat, i, root.comm, root.stream));
+                first = g->rccl.Send(g->m[i].slab, floats_of(i), ncclFloat, 0, g->m[i].comm, g->m[i].stream);
+                if (first == ncclSuccess) first = g->rccl.Recv(g->parts + slab_floats * i, floats_of(i), ncclFloat, i, root.comm, root.stream);
                 g->last_exchange_bytes += floats_of(i) * 4.0;
             }
-            G_NCCL(g, g->rccl.GroupEnd());
+            const ncclResult_t end = g->rccl.GroupEnd();
+            G_NCCL(g, first);
+            G_NCCL(g, end);
         } else {
             for (int i = 1; i < n; ++i) {
                 if (!floats_of(i)) continue;

@@ -375,3 +375,6 @@ def test_bench_multi_rank_code_path_rehearsed_on_one_gpu(scaling):
     assert d["n_gpus"] == 2 and d["rccl"]["world_size"] == 2 and d["rccl"]["backend"] == "gloo" and d["scaling"] == scaling
     assert d["value"] > 0 and d["unit"] == "Mrays/s" and d["config"]["workload"] == "small"
     assert d["config"]["frames_per_step"] == (2 if scaling == "weak" else 1) and "rgb8" in d["rccl"]["exchange"]
+    # the line of an N > 1 run carries a roofline object too: rank 0's last launch, its share of the step's rays
+    rf = d["roofline"]
+    assert rf["kernel"] == "k_render" and rf["kernel_ms"] > 0 and "rank 0" in rf["launch"]
