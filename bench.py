@@ -180,6 +180,9 @@ def main():
     if args.steps is None:
         args.steps = {"c4": 5, "c5": 5}.get(args.workload, 20)
 
+    if os.environ.get("HVRT_BENCH_WATCHDOG"):      # seconds: dump every thread's stack and exit instead of hanging (diagnostics)
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["HVRT_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
     import raytracer_amd as ra
@@ -378,13 +381,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     if world == 1:
-        # per-launch kernel durations come from HIP events on libhvrt's own stream (hvrt_timings.render_ms);
-        # reading them needs the launch finished, so the launches are issued back to back and each is
-        # read after the stream drained -- the wall clock below brackets exactly K launches either way.
-        for _ in range(args.steps):
+        # the K launches are queued back to back (each followed, on the GPU, by the tile order for the next one) and
+        # waited for once; the per-launch kernel durations come from the pairs of HIP events libhvrt records around
+        # every traversal on its own stream (hvrt_render_history keeps the last 32), read after the stream drained.
+        for k in range(args.steps):
             step()
-            ctx.synchronize()
-            kernel_ms.append(ctx.timings().render_ms)
+            if (k + 1) % 32 == 0 or k + 1 == args.steps:
+                kernel_ms.extend(ctx.render_history((k % 32) + 1))
     else:
         for _ in range(args.steps):
             step()

@@ -114,6 +114,12 @@ int hvrt_synchronize(hvrt_ctx* ctx);
  *                their meaning (a ray that misses the grid visits no voxel). */
 int hvrt_set_mode(hvrt_ctx* ctx, int mode);
 int hvrt_get_timings(const hvrt_ctx* ctx, hvrt_timings* out);
+/* Durations of the last asynchronous traversals (hvrt_render_part_device, hvrt_render_batch_part_device, the noalloc
+ * form), for callers that queue several launches and wait once: waits for the stream, then writes up to max_entries
+ * durations in milliseconds (HIP events around each traversal, like hvrt_timings.render_ms), the oldest of them first --
+ * at most the last 32 launches are kept.  Returns the number written, or -1 (hvrt_last_error says why).
+ * No reference counterpart (its render() is synchronous and logs one elapsed time, OctreeLikeRayTracer.cpp:42-118). */
+int hvrt_render_history(hvrt_ctx* ctx, float* ms, int max_entries);
 
 /* Callers that only want the voxel grid itself (the CSR that replaces VoxelGrid::voxels, SceneCreator.cpp:197-281)
  * can keep libhvrt's own derived acceleration data -- empty-space distance field, face bits, per-reference records,

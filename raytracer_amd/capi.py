@@ -25,7 +25,7 @@ SYMBOLS = [
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc", "hvrt_last_hit_count",
-    "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count",
+    "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count", "hvrt_render_history",
     "hvrt_group_create", "hvrt_group_destroy", "hvrt_group_last_error", "hvrt_group_size", "hvrt_group_transport",
     "hvrt_group_member", "hvrt_group_replicate_scene", "hvrt_group_render",
 ]
@@ -112,6 +112,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_render_part_device_noalloc.argtypes = lib.hvrt_render_part_device.argtypes
     lib.hvrt_last_hit_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.hvrt_download.argtypes = [vp, vp, vp, C.c_uint64]
+    lib.hvrt_render_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
     lib.hvrt_group_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
     lib.hvrt_group_destroy.argtypes = [vp]
     lib.hvrt_group_destroy.restype = None
@@ -350,6 +351,14 @@ class Context:
         t = Timings()
         self._ck(self._lib.hvrt_get_timings(self._h, C.byref(t)))
         return t
+
+    def render_history(self, n: int = 32) -> list:
+        """Waits for the stream; durations (ms) of the last (up to n, at most 32) asynchronous traversals, oldest first."""
+        buf = (C.c_float * max(1, n))()
+        got = self._lib.hvrt_render_history(self._h, buf, max(1, n))
+        if got < 0:
+            self._ck(-1)
+        return [float(buf[i]) for i in range(got)]
 
     def set_mode(self, mode: int):
         """0 = the reference's traversal (default), 1 = nearest-hit mode."""

@@ -31,6 +31,11 @@ struct hvrt_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dist_in_flight = false;
     hipEvent_t ev[10] = {};
+    // ev[6] / ev[7] bracket the LAST traversal; every asynchronous render takes the next pair of this ring for them, so
+    // that a caller who queues several launches and waits once can still read each one's duration (hvrt_render_history)
+    static constexpr int RENDER_RING = 32;
+    hipEvent_t render_ring[RENDER_RING][2] = {};
+    uint64_t renders_recorded = 0;
     std::string error;
 
     // mesh
@@ -63,6 +68,8 @@ struct hvrt_ctx {
     // build scratch
     uint32_t* ranges = nullptr;   uint64_t ranges_capacity = 0;
     uint32_t* cnt16 = nullptr;    uint64_t cnt16_capacity = 0;      // 16-bit counters of the count pass, two per word
+    bool wait_for_split = true;            // HVRT_SPLIT_WAIT=0: k_render does not wait for k_render_split's workgroups to be resident
+    uint32_t split_started_total = 0;      // workgroups of all k_render_split launches that report in (wraps; compared as a difference)
     bool narrow_counters = true;   // HVRT_BUILD_NARROW=0; cleared for good once a list of this context outgrew 16 bits
     uint32_t* occ_bits = nullptr; uint64_t occ_bits_capacity = 0;   // one bit per voxel, left by the scan for the distance field
     bool occ_bits_valid = false;
@@ -431,7 +438,12 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     *c->split_hint = 1u;
     if ((e = hipHostGetDevicePointer((void**)&c->split_hint_dev, c->split_hint, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     for (auto& ev : c->ev)
-        if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+        if (&ev != &c->ev[6] && &ev != &c->ev[7] && (e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    for (auto& pair : c->render_ring)
+        for (auto& ev : pair)
+            if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+    c->ev[6] = c->render_ring[0][0];        // (aliases: the ring owns them)
+    c->ev[7] = c->render_ring[0][1];
     if ((e = hipMalloc((void**)&c->stats, STATS_STATUS * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     c->stats_capacity = STATS_STATUS;
     if ((e = hipMalloc((void**)&c->tile_counter, 256)) != hipSuccess) return bail("hipMalloc", e);
@@ -442,6 +454,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if (const char* v = getenv("HVRT_BUILD_REUSE")) c->reuse_arrays = atoi(v) != 0;
     if (const char* v = getenv("HVRT_BUILD_NARROW")) c->narrow_counters = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_SPLIT_WAIT")) c->wait_for_split = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_ABORT_US")) {
@@ -508,7 +521,9 @@ void hvrt_destroy(hvrt_ctx* c) {
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
+    c->ev[6] = c->ev[7] = nullptr;          // aliases of ring entries
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto& pair : c->render_ring) for (auto& ev : pair) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : c->cam_ev) if (ev) (void)hipEventDestroy(ev);
     if (c->cam_host) (void)hipHostFree(c->cam_host);
     if (c->split_hint) (void)hipHostFree(c->split_hint);
@@ -536,6 +551,12 @@ int hvrt_set_stream(hvrt_ctx* c, void* hip_stream) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));   // nothing of ours may still run on the old stream
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return HVRT_OK;
+}
+
+static void next_render_events(hvrt_ctx* c) {
+    const int k = (int)(c->renders_recorded++ % hvrt_ctx::RENDER_RING);
+    c->ev[6] = c->render_ring[k][0];
+    c->ev[7] = c->render_ring[k][1];
 }
 
 int hvrt_synchronize(hvrt_ctx* c) {
@@ -1010,12 +1031,14 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     ra.order = reuse ? c->tile_order : nullptr;
     ra.split_tiles = c->split_tiles;
     ra.n_split = c->order_blocks + order_blocks;
+    ra.split_started = nullptr;
     ra.abandoned = c->abandoned;
     ra.n_abandoned = c->tile_counter + 1;
     ra.abort_ticks = c->abort_ticks;
     ra.tile_cost = c->tile_cost;
     ra.cost_sum = c->cost_sum + c->cost_parity;
     ra.seg_slots = nullptr; ra.seg = 0;
+    next_render_events(c);
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     if (!c->queue_clean) {
         HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // queue head, abandoned count, [8..15] the heads of segment launches
@@ -1028,8 +1051,16 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             // the tiles too long for one wave go first and beside the others, on the second stream
             HIP_TRY(c, hipEventRecord(c->ev_split_fork, s));
             HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_split_fork, 0));
-            HIP_TRY(c, launch_render_split(scene_of(c), ra, c->n_cus, c->aux_stream));
+            RenderArgs rsplit = ra;
+            rsplit.split_started = c->wait_for_split ? c->tile_counter + 48 : nullptr;      // a word of the 64-word scratch, never reset
+            uint32_t nb = 0;
+            HIP_TRY(c, launch_render_split(scene_of(c), rsplit, c->n_cus, c->aux_stream, &nb));
             HIP_TRY(c, hipEventRecord(c->ev_split_join, c->aux_stream));
+            if (rsplit.split_started && nb) {
+                // k_render's persistent waves would otherwise take every slot before the split kernel is on (see k_wait_split_started)
+                c->split_started_total += nb;
+                HIP_TRY(c, launch_wait_split_started(rsplit.split_started, c->split_started_total, 100u, s));
+            }
         }
         if (plan && plan->n > 1 && plan->n <= 8 && n_frames == 1) {
             // several launches over consecutive row ranges of this one queue; the long tiles (the queue's head) and the
@@ -1122,6 +1153,21 @@ int hvrt_download(hvrt_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
     return hvrt_synchronize(c);
 }
 
+int hvrt_render_history(hvrt_ctx* c, float* ms, int max_entries) {
+    if (!c) return -1;
+    if (bind(c)) return -1;
+    if (!ms || max_entries < 1) { fail(c, HVRT_ERR_INVALID, "render_history: no room for an entry"); return -1; }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { fail(c, HVRT_ERR_HIP, "render_history: hipStreamSynchronize failed"); return -1; }
+    if (c->render_pending) { c->tm.render_ms = ms_between(c->ev[6], c->ev[7]); c->render_pending = false; }
+    uint64_t n = c->renders_recorded < (uint64_t)hvrt_ctx::RENDER_RING ? c->renders_recorded : (uint64_t)hvrt_ctx::RENDER_RING;
+    if (n > (uint64_t)max_entries) n = (uint64_t)max_entries;
+    for (uint64_t i = 0; i < n; ++i) {                 // oldest of the n first
+        const int k = (int)((c->renders_recorded - n + i) % hvrt_ctx::RENDER_RING);
+        ms[i] = ms_between(c->render_ring[k][0], c->render_ring[k][1]);
+    }
+    return (int)n;
+}
+
 int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp,
                                     uint32_t seed, int tile_rows, int part, int n_parts, void* d_rgb, void* d_hit_id,
                                     void* d_t, void* d_counters) {
@@ -1166,6 +1212,7 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
     HIP_TRY(c, hipMemsetAsync(sp, 0, 16, s));
     k_store_frame<<<1, 64, 0, s>>>(*frame, (float*)d_frame);
     HIP_TRY(c, hipGetLastError());
+    next_render_events(c);
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, false, s));
     HIP_TRY(c, hipEventRecord(c->ev[7], s));

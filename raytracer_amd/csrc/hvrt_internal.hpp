@@ -73,6 +73,7 @@ struct RenderArgs {
     // k_render_split, 16 waves per tile (split_tiles[0, *n_split), both written by k_order_place; with order).
     const uint32_t* split_tiles;
     const uint32_t* n_split;
+    uint32_t* split_started;      // (nullable) k_render_split: every workgroup adds 1 when it starts (launch_wait_split_started)
     // k_render gives up on a tile whose rays are still inside long lists abort_ticks after they set out and
     // appends it to abandoned[*n_abandoned++] (zeroed before the launch); a k_render_split launch behind it
     // renders those tiles (split_tiles = abandoned, n_split = n_abandoned).
@@ -147,7 +148,11 @@ hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s);
 // abortable: the kernel may give up on over-long tiles (ra.abandoned); a launch_render_split over that list must follow
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
-hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s);
+hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups = nullptr);
+// One wave that waits (at most timeout_us) until *started has reached `target` (wrap-around compare): queued in front of
+// a k_render whose k_render_split runs beside it on another stream, so that the split kernel's workgroups are resident
+// before k_render's persistent waves take every slot there is.
+hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_t timeout_us, hipStream_t s);
 // split_tiles <- the tiles for k_render_split; order <- the others: long tiles (cost > 2.5 x mean) first, the
 // rest behind them in natural order.  block_count: 2 x (ceil(n_tiles / 256) + 1) u32 of scratch; afterwards
 // block_count[ceil(n_tiles / 256)] is the number of split tiles (0 when may_split is false).  *wants_split

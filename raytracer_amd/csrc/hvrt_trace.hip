@@ -1056,6 +1056,7 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t tiles_frame = tiles_x * tiles_y;
+    if (ra.split_started && threadIdx.x == 0) atomicAdd(ra.split_started, 1u);      // "this workgroup has a place on the GPU"
     const uint32_t n_items = *ra.n_split * 16u;
     const uint32_t wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
     uint64_t tot_nv = 0, tot_nt = 0;
@@ -1312,7 +1313,28 @@ hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bo
     return hipGetLastError();
 }
 
-hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s) {
+// k_render and k_render_split become eligible at the same moment (an event on k_render's stream releases the other).
+// Launched one by one with the host waiting in between, the split kernel happened to reach the GPU some 20 us ahead:
+// its workgroups took their places, those without work left at once, and k_render's filled in around the rest.  Queued
+// back to back, k_render wins the race by 6 us, its persistent waves take every wave slot, and the split kernel only
+// gets on when they retire -- it then ended 130 us AFTER k_render (config 2: 1.78 ms per launch instead of 1.65).  This
+// wave holds k_render's stream until every workgroup of the split kernel has reported in (or timeout_us have passed --
+// an exit every run reaches).
+__global__ __launch_bounds__(64) void k_wait_split_started(uint32_t* started, uint32_t target, uint32_t timeout_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while ((int)(atomicAdd(started, 0u) - target) < 0) {
+        if (wall_clock64() - t0 > (unsigned long long)timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_t timeout_us, hipStream_t s) {
+    k_wait_split_started<<<1, 64, 0, s>>>(started, target, timeout_us * 100u);      // wall_clock64 ticks at 100 MHz
+    return hipGetLastError();
+}
+
+hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups) {
+    if (n_workgroups) *n_workgroups = 0;
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.order) return hipSuccess;
     uint64_t blocks = n_tiles * 4;                         // 16 waves per tile, were every tile split
@@ -1320,6 +1342,7 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
     if (blocks > cap) blocks = cap;
     const bool il = sc.ref_rec != nullptr;
     const unsigned nb = (unsigned)blocks;
+    if (n_workgroups) *n_workgroups = nb;
 #define HVRT_LAUNCH(C, I, N) k_render_split<C, I, N><<<nb, 256, 0, s>>>(sc, ra)
     if (ra.nearest) {
         if (ra.counters) { if (il) HVRT_LAUNCH(true, true, true); else HVRT_LAUNCH(true, false, true); }

@@ -44,5 +44,18 @@ for i in range(reps + 2):
     ctx.render_part_device(cam, W, H, spp, 1, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
     ctx.synchronize()
     if i >= 2: ms.append(ctx.timings().render_ms)
+if os.environ.get("HVRT_TIME_QUEUED"):        # the same launches queued back to back, waited for once (hvrt_render_history)
+    import time
+    t0 = time.perf_counter()
+    for i in range(reps):
+        ctx.render_part_device(cam, W, H, spp, 1, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
+    q = ctx.render_history(reps)
+    wall = (time.perf_counter() - t0) * 1e3 / reps
+    print(f"queued: wall {wall:.3f} ms per launch; per launch " + " ".join(f"{v:.3f}" for v in q), flush=True)
+    t0 = time.perf_counter()
+    for i in range(reps):
+        ctx.render_part_device(cam, W, H, spp, 1, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
+        ctx.synchronize()
+    print(f"waited for one by one: wall {(time.perf_counter() - t0) * 1e3 / reps:.3f} ms per launch", flush=True)
 print(f"render {W}x{H} spp {spp}: mean {np.mean(ms):.3f} ms min {np.min(ms):.3f} ms -> {W*H*spp/np.mean(ms)/1e3:.1f} Mrays/s; checksum hit {int(hit.long().sum())}", flush=True)
 ctx.close()

@@ -228,6 +228,38 @@ def test_batch_launch_equals_single_launches_and_order_changes_nothing(ctx, n_pa
         ctx.render_batch_part_device(cams * 9, W, H, 1, 0, tile_rows, part, n_parts, slab, d_rgb=batch.data_ptr())
 
 
+def test_launches_queued_without_waiting_keep_their_durations_and_their_bytes(ctx):
+    """hvrt_render_history: launches queued back to back (what bench.py's timed region does) are each bracketed by their
+    own pair of events -- the last 32 are kept -- and every one of them writes the frame the first one wrote."""
+    import torch
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx = setup_scene(ctx, tris, (24, 24, 24))
+    W, H = 320, 200
+    cam = capi.make_camera_frame(*capi.default_camera(mn, mx, "front"))
+    dev = torch.device("cuda:0")
+    first = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, d_rgb=first.data_ptr())
+    ctx.synchronize()
+    want = first.cpu().numpy().view(np.uint32)
+    outs = [torch.zeros_like(first) for _ in range(5)]
+    torch.cuda.synchronize()
+    for o in outs:
+        ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, d_rgb=o.data_ptr())        # no wait in between
+    ms = ctx.render_history(5)
+    assert len(ms) == 5 and all(0.0 < m < 100.0 for m in ms), ms
+    assert ms[-1] == pytest.approx(ctx.timings().render_ms, abs=1e-6)                 # the last launch is hvrt_timings' one
+    for k, o in enumerate(outs):
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), want), f"queued launch {k} differs"
+    assert len(ctx.render_history(3)) == 3
+    for _ in range(40):
+        ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, d_rgb=outs[0].data_ptr())
+    assert len(ctx.render_history(64)) == 32                                           # the ring holds 32
+    assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), want)
+    with pytest.raises(capi.HvrtError):
+        ctx._ck(0 if ctx._lib.hvrt_render_history(ctx._h, None, 4) >= 0 else -1)
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_split_tiles_change_nothing(ctx, mode):
     """From the second launch of a shape on, tiles that took longer than a balanced launch would are rendered by
