@@ -69,6 +69,7 @@ struct hvrt_ctx {
     uint32_t* ranges = nullptr;   uint64_t ranges_capacity = 0;
     uint32_t* cnt16 = nullptr;    uint64_t cnt16_capacity = 0;      // 16-bit counters of the count pass, two per word
     bool wait_for_split = true;            // HVRT_SPLIT_WAIT=0: k_render does not wait for k_render_split's workgroups to be resident
+    uint32_t order_split_hint = 0;         // tiles that qualified for k_render_split when the order in use was queued (0: not known)
     uint32_t split_started_total = 0;      // workgroups of all k_render_split launches that report in (wraps; compared as a difference)
     bool narrow_counters = true;   // HVRT_BUILD_NARROW=0; cleared for good once a list of this context outgrew 16 bits
     uint32_t* occ_bits = nullptr; uint64_t occ_bits_capacity = 0;   // one bit per voxel, left by the scan for the distance field
@@ -1054,7 +1055,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             RenderArgs rsplit = ra;
             rsplit.split_started = c->wait_for_split ? c->tile_counter + 48 : nullptr;      // a word of the 64-word scratch, never reset
             uint32_t nb = 0;
-            HIP_TRY(c, launch_render_split(scene_of(c), rsplit, c->n_cus, c->aux_stream, &nb));
+            HIP_TRY(c, launch_render_split(scene_of(c), rsplit, c->n_cus, c->aux_stream, &nb, c->order_split_hint));
             HIP_TRY(c, hipEventRecord(c->ev_split_join, c->aux_stream));
             if (rsplit.split_started && nb) {
                 // k_render's persistent waves would otherwise take every slot before the split kernel is on (see k_wait_split_started)
@@ -1105,6 +1106,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
                                       c->cost_sum + (c->cost_parity ^ 1), s));
         c->order_ahead = true;
         c->order_may_split = may_split;
+        c->order_split_hint = *(volatile uint32_t*)c->split_hint;      // as of the last order build that has run: sizes the next k_render_split
         c->cost_parity ^= 1;
     } else {
         c->cost_parity ^= 1;

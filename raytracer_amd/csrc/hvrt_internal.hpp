@@ -148,7 +148,8 @@ hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s);
 // abortable: the kernel may give up on over-long tiles (ra.abandoned); a launch_render_split over that list must follow
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
-hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups = nullptr);
+hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups = nullptr,
+                               uint32_t expected_tiles = 0);
 // One wave that waits (at most timeout_us) until *started has reached `target` (wrap-around compare): queued in front of
 // a k_render whose k_render_split runs beside it on another stream, so that the split kernel's workgroups are resident
 // before k_render's persistent waves take every slot there is.

@@ -1333,13 +1333,17 @@ hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_
     return hipGetLastError();
 }
 
-hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups) {
+hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups,
+                               uint32_t expected_tiles) {
     if (n_workgroups) *n_workgroups = 0;
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.order) return hipSuccess;
     uint64_t blocks = n_tiles * 4;                         // 16 waves per tile, were every tile split
     const uint64_t cap = (uint64_t)n_cus * 4;
     if (blocks > cap) blocks = cap;
+    // (the caller's idea of how many tiles there are, when it has one: twice the workgroups they need, 16 at least --
+    // the items are dealt round-robin, so a count that was too low costs time, not tiles)
+    if (expected_tiles && (uint64_t)expected_tiles * 8u < blocks) blocks = expected_tiles * 8u < 16u ? 16u : expected_tiles * 8u;
     const bool il = sc.ref_rec != nullptr;
     const unsigned nb = (unsigned)blocks;
     if (n_workgroups) *n_workgroups = nb;
