@@ -5,7 +5,6 @@ with two ranks that share the GPU and talk over gloo -- more moving parts than a
 end runs `pytest -x`.  A rank that stalls dumps its stacks and exits (HVRT_BENCH_WATCHDOG) instead of holding the run.
 """
 import os
-import socket
 
 import pytest
 
@@ -14,7 +13,8 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_multi_rank_code_path_rehearsed_on_one_gpu(scaling):
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU), rehearsed on this box's one
+    """bench.py as it runs for N > 1 (torch.distributed.run, one rank per GPU; the launcher picks its own rendezvous port here,
+    the driver passes --master-addr / --master-port -- bench.py reads RANK / WORLD_SIZE / MASTER_* either way), rehearsed on this box's one
     GPU: HVRT_BENCH_REHEARSE=1 puts both ranks on device 0 and stages the collectives through gloo.  What this pins is
     that the N > 1 code of bench.py -- scene replication, 8-bit batch pipeline (weak) / one frame over all ranks (strong),
     max-over-ranks timing, the JSON line -- runs end to end; the numbers of such a run mean nothing."""
@@ -22,13 +22,9 @@ def test_bench_multi_rank_code_path_rehearsed_on_one_gpu(scaling):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     env = dict(os.environ, HVRT_BENCH_REHEARSE="1", HVRT_BENCH_WATCHDOG="150")      # a rank that stalls dumps its stacks and exits
-    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+                        "--nproc-per-node", "2", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--workload", "small", "--scaling", scaling], capture_output=True, text=True, timeout=240, env=env, cwd=root)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
