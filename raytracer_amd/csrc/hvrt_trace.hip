@@ -572,7 +572,16 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                         else if (any_lane(tmx < ey) == 0ull)
                             HVRT_TWO_AXIS_RUN(tmy, tdy, ry, fsy, tmz, tdz, fsz, !(tmx < preA), (void)0);
                     }
-#if defined(HVRT_DIAG) && HVRT_DIAG == 21   // steps of two-axis runs | general steps of runs with k >= 4
+#if defined(HVRT_DIAG) && HVRT_DIAG == 23   // general steps of runs with k >= 4: every lane has SOME far axis by the estimate | not
+                    // (config 2: 0.16 | 29.3 per ray -- the runs that fall back hold a lane in which all three axes step, so
+                    // a far axis chosen per lane would convert next to nothing; runs cut into quarters were tried: slower)
+                    if (!ran && k >= 4) {
+                        const float kf2 = (float)k;
+                        const float ex2 = tmx + kf2 * tdx, ey2 = tmy + kf2 * tdy;
+                        const bool some = (ex2 < tmz && ey2 < tmz) || (ex2 < tmy) || !(tmx < ey2);
+                        if (any_lane(!some) == 0ull) r.nv += (uint32_t)k; else r.nt += (uint32_t)k;
+                    }
+#elif defined(HVRT_DIAG) && HVRT_DIAG == 21   // steps of two-axis runs | general steps of runs with k >= 4
                     if (ran) r.nv += (uint32_t)k; else if (k >= 4) r.nt += (uint32_t)k;
 #elif defined(HVRT_DIAG) && HVRT_DIAG == 22   // general steps of runs with k < 4 | runs (consults that stepped)
                     if (k < 4) r.nv += (uint32_t)k;

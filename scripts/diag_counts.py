@@ -25,7 +25,8 @@ print('render_ms', ctx.timings().render_ms)
 n = W * H
 print(f"raw counters / rays: first {cnt[0]/n:.3f} second {cnt[1]/n:.3f}   (DIAG 11: cooperative | per-lane chunks per ray slot; "
       f"12: cooperative | per-lane wave test iterations per ray slot; 13: cooperative iterations | tests the lanes wanted; "
-      f"21: steps in two-axis runs | general steps of runs with k >= 4; 22: general steps of runs with k < 4 | runs)")
+      f"21: steps in two-axis runs | general steps of runs with k >= 4; 22: general steps of runs with k < 4 | runs; "
+      f"23: general steps of runs with k >= 4 where every lane has some far axis | where a lane has none)")
 print(f"[DIAG=31: clocks waiting for the queue head in all {cnt[0]:.4g}, pulls {cnt[1]:.4g} -> {cnt[0]/max(cnt[1],1):.0f} clocks per pull]")
 print(f"[DIAG=32: wave lifetimes summed {cnt[0]:.4g} clocks, inside tiles {cnt[1]:.4g} -> {cnt[1]/max(cnt[0],1):.3f} of a wave's life is tile work; "
       f"mean lifetime {cnt[0]/8192:.4g} clocks per wave (8192 resident waves)]")
