@@ -1041,6 +1041,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     ra.seg_slots = nullptr; ra.seg = 0;
     next_render_events(c);
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    const bool queued_behind_ev6 = !c->queue_clean;
     if (!c->queue_clean) {
         HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // queue head, abandoned count, [8..15] the heads of segment launches
         HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
@@ -1050,8 +1051,10 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         const bool may_split = c->order_may_split;
         if (may_split) {
             // the tiles too long for one wave go first and beside the others, on the second stream
-            HIP_TRY(c, hipEventRecord(c->ev_split_fork, s));
-            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_split_fork, 0));
+            // (the fork is the launch's own first timing event when nothing was queued behind it: one packet fewer in the stream)
+            hipEvent_t fork = c->ev[6];
+            if (queued_behind_ev6) { fork = c->ev_split_fork; HIP_TRY(c, hipEventRecord(fork, s)); }
+            HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, fork, 0));
             RenderArgs rsplit = ra;
             rsplit.split_started = c->wait_for_split ? c->tile_counter + 48 : nullptr;      // a word of the 64-word scratch, never reset
             uint32_t nb = 0;
