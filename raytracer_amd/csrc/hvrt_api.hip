@@ -3,6 +3,7 @@
 // kernel that fills its camera slot); the kernels live in hvrt_build.hip / hvrt_trace.hip.  No CPU fallback
 // exists: every entry point either runs on the GPU or returns an error.
 #include "hvrt_internal.hpp"
+#include <unistd.h>
 
 #include <float.h>
 #include <math.h>
@@ -105,6 +106,7 @@ struct hvrt_ctx {
     // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
     // Read without waiting -- a stale answer only delays the switch by a launch.  Starts at "some".
     uint32_t* split_hint = nullptr;
+    uint64_t* stats_host = nullptr;        // pinned landing place of a build's eight statistics words (a copy into pageable memory waits inside hipMemcpyAsync)
     uint32_t* split_hint_dev = nullptr;    // the same word as the device addresses it
     unsigned long long* cost_sum = nullptr;   // 2 x u64: this launch's and the previous launch's sum of tile costs
     int cost_parity = 0;
@@ -424,8 +426,13 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     c->stream = c->own_stream;
     if ((e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     {
+        // Normal priority unless HVRT_DF_LOW_PRIORITY=1.  The distance field used to run on a lowest-priority stream, to
+        // keep out of the scatter's way; but a low-priority hardware queue is what the GPU's scheduler serves last when
+        // the card is shared: with three processes holding queues on one MI355X (a test run: pytest and two bench ranks)
+        // each build then took 20 to 30 SECONDS, its other phases long done and this stream still "busy".
         int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
+        const char* low = getenv("HVRT_DF_LOW_PRIORITY");
+        if (!(low && atoi(low) != 0) || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = 0; }
         if ((e = hipStreamCreateWithPriority(&c->df_stream, hipStreamNonBlocking, least)) != hipSuccess) return bail("hipStreamCreate", e);
     }
     if ((e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
@@ -435,8 +442,9 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipHostMalloc((void**)&c->split_hint, 64, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
+    if ((e = hipHostMalloc((void**)&c->split_hint, 128, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     *c->split_hint = 1u;
+    c->stats_host = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(c->split_hint) + 64);      // 8 words of the same pinned block
     if ((e = hipHostGetDevicePointer((void**)&c->split_hint_dev, c->split_hint, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     for (auto& ev : c->ev)
         if (&ev != &c->ev[6] && &ev != &c->ev[7] && (e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
@@ -721,10 +729,34 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
         return HVRT_OK;
     };
 
+    static const bool trace_build = getenv("HVRT_TRACE_BUILD") != nullptr;      // diagnostics: where a build is, on stderr
+    auto note = [&](const char* what) { if (trace_build) { fprintf(stderr, "[hvrt_build_grid %p] %s\n", (void*)c, what); fflush(stderr); } };
     uint64_t h_stats[8];
     auto read_stats = [&]() -> int {
-        HIP_TRY(c, hipMemcpyAsync(h_stats, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(c->stats_host, c->stats, sizeof h_stats, hipMemcpyDeviceToHost, s));
+        note("waiting for the stream");
+        if (trace_build) {
+            // which phase a build that does not come back is in: the events recorded behind the phases, after 20 s
+            const auto t0 = std::chrono::steady_clock::now();
+            while (hipStreamQuery(s) == hipErrorNotReady) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    const int ks[] = { 0, 1, 2, 3, 4, 5, 8 };
+                    const char* names[] = { "start", "count", "scan", "(fill queued)", "fill", "order", "derived data" };
+                    for (int i = 0; i < 7; ++i)
+                        fprintf(stderr, "[hvrt_build_grid %p] after 20 s: event behind '%s' %s\n", (void*)c, names[i],
+                                hipEventQuery(c->ev[ks[i]]) == hipSuccess ? "reached" : "NOT reached");
+                    fprintf(stderr, "[hvrt_build_grid %p] distance-field stream %s\n", (void*)c,
+                            hipStreamQuery(c->df_stream) == hipSuccess ? "idle" : "busy");
+                    fflush(stderr);
+                    break;
+                }
+                usleep(500);
+            }
+            (void)hipGetLastError();
+        }
         HIP_TRY(c, hipStreamSynchronize(s));
+        memcpy(h_stats, c->stats_host, sizeof h_stats);
+        note("stream drained");
         if (h_stats[5]) return fail(c, HVRT_ERR_HIP, "build_grid: the offset scan gave up waiting for a chunk (device fault?)");
         // stats[0] is exact in 64 bits; the offsets are 32-bit sums and only meaningful when it fits
         if (h_stats[0] > 0xFFFFFFFFull)
@@ -763,12 +795,15 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     for (;;) {
         const bool narrow = c->narrow_counters;
         (void)join_distance_field(c, s);        // (second round only: the first one's field is being recomputed)
+        note("queueing count + scan");
         if (int r = front(narrow)) return r;
+        note("count + scan queued");
         const uint64_t live_cap = c->reuse_arrays ? ref_capacity_of(c, !c->defer_accel) : 0;
         bool went_ahead = live_cap > 0;
         if (went_ahead) {
             const RefCount rc = { c->stats, 0, live_cap };
             if (int r = tail(rc)) return r;
+            note("scatter, order and derived data queued");
         }
         if (int r = read_stats()) return r;
         if (narrow && h_stats[0] != h_stats[7]) {      // a 16-bit counter carried: nothing was scattered, count again

@@ -22,11 +22,11 @@ def test_bench_multi_rank_code_path_rehearsed_on_one_gpu(scaling):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HVRT_BENCH_REHEARSE="1", HVRT_BENCH_WATCHDOG="150")      # a rank that stalls dumps its stacks and exits
+    env = dict(os.environ, HVRT_BENCH_REHEARSE="1", HVRT_BENCH_WATCHDOG="150", HVRT_TRACE_BUILD="1")      # a rank that stalls dumps its stacks and exits
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
                         "--nproc-per-node", "2", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--workload", "small", "--scaling", scaling], capture_output=True, text=True, timeout=240, env=env, cwd=root)
-    assert p.returncode == 0, p.stderr[-3000:]
+    assert p.returncode == 0, p.stderr[-6000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
     d = json.loads(lines[0])
