@@ -377,7 +377,7 @@ uint64_t ref_capacity_of(const hvrt_ctx* c, bool with_derived_data) {
 
 float ms_between(hipEvent_t a, hipEvent_t b) {
     float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return -1.0f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) { (void)hipGetLastError(); return -1.0f; }      // (an event never recorded: not an error to carry along)
     return ms;
 }
 
