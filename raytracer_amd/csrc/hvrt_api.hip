@@ -26,7 +26,7 @@ struct hvrt_ctx {
     hipStream_t stream = nullptr;       // the stream all work is issued on (own_stream unless hvrt_set_stream)
     hipStream_t own_stream = nullptr;
     hipStream_t aux_stream = nullptr;   // k_render_split runs here, beside k_render
-    hipStream_t df_stream = nullptr;    // the distance field is built here (lowest priority), beside fill / order / records
+    hipStream_t df_stream = nullptr;    // the distance field is built here, beside fill / order / records
     hipStream_t copy_stream = nullptr;  // hvrt_render: the rows one launch completed go to the host here while the next launch traces
     hipEvent_t ev_seg[8] = {};
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
