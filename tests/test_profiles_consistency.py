@@ -1,0 +1,92 @@
+"""The evidence under profiles/ is self-consistent: every fraction a bench line quotes can be recomputed from the counter
+files beside it, none exceeds 1, and the kernel-trace summary agrees with the duration the line measured with HIP events.
+No GPU: this reads committed files only (round 1's review asked for exactly this property; the test keeps it true when
+the profiles are re-installed)."""
+import csv
+import json
+import os
+
+import pytest
+
+P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+KERNEL = "k_render<false, true, false, false>"
+N_SIMD, N_CU, N_XCD = 1024, 256, 8
+PIXELS = {"c2": 3840 * 2160, "c3": 3840 * 2160, "c4": 7680 * 4320 * 16}
+
+
+def _load(name):
+    with open(os.path.join(P, name)) as f:
+        return json.load(f)
+
+
+def _kernel(pmc):
+    return [v for n, v in pmc.items() if KERNEL in n][0]
+
+
+@pytest.mark.parametrize("w", ["c2", "c3", "c4"])
+def test_traffic_json_follows_from_the_counter_files(w):
+    t = _load("traffic.json")[w]
+    k = _kernel(_load(f"r2_pmc_{w}.json"))
+    m = lambda c: k[c]["mean"]
+    cyc = m("GRBM_GUI_ACTIVE") / N_XCD
+    assert t["kernel_cycles"] == pytest.approx(cyc)
+    # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md), so reads are doubled; KB -> bytes
+    assert t["k_render_hbm_bytes_per_launch"] == pytest.approx((2 * m("FETCH_SIZE") + m("WRITE_SIZE")) * 1024)
+    assert t["valu_issue_frac"] == pytest.approx(m("SQ_INSTS_VALU") * 2.2 / N_SIMD / cyc, abs=6e-4)
+    assert t["salu_issue_frac"] == pytest.approx(m("SQ_INSTS_SALU") / N_CU / cyc, abs=6e-4)
+    assert t["vmem_return_frac"] == pytest.approx(m("SQ_INSTS_VMEM_RD") * 16.3 / N_CU / cyc, abs=6e-4)
+    mix = _load("r2_valu_mix.json")["mean_issue_clocks_per_instruction"]
+    assert t["valu_issue_frac_mix_raw"] == pytest.approx(m("SQ_INSTS_VALU") * mix / N_SIMD / cyc, abs=6e-4)
+    assert t["valu_issue_frac_mix"] == pytest.approx(min(1.0, t["valu_issue_frac_mix_raw"]), abs=6e-4)
+    for key in ("valu_issue_frac", "valu_issue_frac_mix", "salu_issue_frac", "vmem_return_frac"):
+        assert 0.0 < t[key] <= 1.0, key
+
+
+@pytest.mark.parametrize("w", ["c2", "c3", "c4"])
+def test_bench_line_quotes_traffic_json_and_its_own_clock(w):
+    t = _load("traffic.json")[w]
+    d = _load(f"r2_bench_{w}.json")
+    r = d["roofline"]
+    assert d["config"]["workload"] == w and d["n_gpus"] == 1 and d["unit"] == "Mrays/s" and d["vs_baseline"] is None
+    assert d["value"] == pytest.approx(PIXELS[w] / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
+    assert r["kernel_ms"] <= d["ms_per_step"]
+    cands = r["candidates"]
+    assert r["bound"] + "_frac" == max(cands, key=cands.get) and r["frac"] == cands[r["bound"] + "_frac"] <= 1.0
+    assert r["frac"] == t[r["bound"] + "_frac"] and r["achieved"] / r["peak"] == pytest.approx(r["frac"])
+    assert r["traffic"] == pytest.approx(t["k_render_hbm_bytes_per_launch"])
+    assert r["hbm_frac"] == pytest.approx(r["traffic"] / (r["kernel_ms"] * 1e-3) / 8e12)
+    requested = r["algorithmic_bytes_per_ray"] * PIXELS[w]
+    assert r["reuse_factor"] == pytest.approx(requested / r["traffic"])
+    assert r["requested_GBps"] == pytest.approx(requested / (r["kernel_ms"] * 1e-3) / 1e9)
+    # 8 B per visited voxel + 40 B per triangle test + the pixel's outputs
+    s = d["scene"]
+    spp = d["config"]["spp"]
+    assert r["algorithmic_bytes_per_ray"] == pytest.approx(8 * s["voxels_per_ray"] + 40 * s["tri_tests_per_ray"] + 20.0 / spp)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+
+
+def test_kernel_trace_agrees_with_the_events():
+    """rocprofv3 --kernel-trace --stats of the same command: the traversal kernel's average is what the line's HIP events
+    measured, less the few microseconds of packets the events also bracket (the wait for the split kernel, its join)."""
+    d = _load("r2_bench_c2_under_rocprof.json")
+    with open(os.path.join(P, "r2_bench_c2_kernel_stats.csv")) as f:
+        rows = [r for r in csv.DictReader(f) if KERNEL in r["Name"]]
+    assert len(rows) == 1
+    calls, avg_ms = int(rows[0]["Calls"]), float(rows[0]["AverageNs"]) * 1e-6
+    assert calls == d["steps"] + d["warmup"]
+    ev_ms = d["roofline"]["kernel_ms"]
+    assert avg_ms <= ev_ms <= avg_ms * 1.03, (avg_ms, ev_ms)
+
+
+def test_build_line_quotes_the_build_counters():
+    t = _load("traffic.json")["c5"]
+    d = _load("r2_bench_c5.json")
+    r = d["roofline"]
+    assert d["config"]["workload"] == "c5" and d["unit"] == "ms" and d["higher_is_better"] is False
+    assert r["traffic"] == pytest.approx(t["build_hbm_bytes"])
+    s = d["scene"]
+    b_build = 72.0 * d["config"]["triangles"] + 12.0 * 1024 ** 3 + 20.0 * s["refs"]
+    assert r["algorithmic_bytes"] == pytest.approx(b_build)
+    assert r["frac"] == pytest.approx(b_build / (r["csr_ms"] * 1e-3) / 8e12) and r["frac"] <= 1.0
+    # the counters say the CSR's kernels move the algorithmic bytes and little more (no wasted re-reads)
+    assert 0.9 < r["traffic"] / b_build < 1.1
