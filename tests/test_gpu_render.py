@@ -258,6 +258,29 @@ def test_launches_queued_without_waiting_keep_their_durations_and_their_bytes(ct
     assert np.array_equal(outs[0].cpu().numpy().view(np.uint32), want)
     with pytest.raises(capi.HvrtError):
         ctx._ck(0 if ctx._lib.hvrt_render_history(ctx._h, None, 4) >= 0 else -1)
+    # the same with tiles that go to k_render_split (a scene with long lists: launches 2.. of a shape hand the long tiles to
+    # the second kernel, which k_render's stream waits for -- k_wait_split_started -- before its persistent waves fill the GPU)
+    tris = meshgen.skewed_statue(24, 120)
+    sc, mn, mx = setup_scene(ctx, tris, (32, 32, 32))
+    W, H = 640, 360
+    cam = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=W / H))
+    exp = sc.render(cam, W, H, threads=16)
+    want_rgb = np.ascontiguousarray(exp[0], np.float32).reshape(H, W, 3).view(np.uint32)
+    outs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in range(6)]
+    hits = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in range(6)]
+    torch.cuda.synchronize()
+    for _ in range(2):                                   # history: from the second launch on some tiles are split
+        ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, d_rgb=outs[0].data_ptr())
+        ctx.synchronize()
+    outs[0].zero_()
+    torch.cuda.synchronize()
+    for o, h in zip(outs, hits):
+        ctx.render_part_device(cam, W, H, 1, 0, H, 0, 1, d_rgb=o.data_ptr(), d_hit=h.data_ptr())
+    assert len(ctx.render_history(6)) == 6
+    want_hit = np.asarray(exp[1]).reshape(H, W).astype(np.uint32)
+    for k, (o, h) in enumerate(zip(outs, hits)):
+        assert np.array_equal(o.cpu().numpy().view(np.uint32), want_rgb), f"queued launch {k} with split tiles: rgb differs from the oracle"
+        assert np.array_equal(h.cpu().numpy().view(np.uint32), want_hit), f"queued launch {k} with split tiles: hit ids differ"
 
 
 @pytest.mark.parametrize("mode", [0, 1])
