@@ -113,6 +113,19 @@ int hvrt_synchronize(hvrt_ctx* ctx);
  *                CPU restatement and against brute force over all triangles.  Shading, outputs and counters keep
  *                their meaning (a ray that misses the grid visits no voxel). */
 int hvrt_set_mode(hvrt_ctx* ctx, int mode);
+/* Which voxels of a triangle's bounding-box range list it, for all later hvrt_build_grid calls.
+ *   0 (default)  all of them: the reference's voxelizer (SceneCreator.cpp:197-281), the only rule under which the CSR is
+ *                the reference's grid bit for bit.
+ *   1            those the triangle overlaps, by the separating-axis test the reference declares and never defines
+ *                (GeometryUtils.h:19, triangleIntersectsBox): the voxel grown by 2^-10 of its half size against the
+ *                triangle -- three box normals, the triangle's normal, nine edge x axis products.  An extension: every
+ *                list is a subset of the list rule 0 builds (fewer tests per ray); nothing in the reference pins it, it
+ *                is checked against the CPU restatement (bit-identical CSR) and, in nearest-hit mode, against the frames
+ *                of a rule-0 grid.  In the reference's own traversal mode (first voxel with any hit) frames may differ
+ *                from the reference's: there a hit can be found in a voxel the triangle only shares a bounding box with.
+ *                Geometry outside the grid (the reference clamps its voxel indices into the border voxels) is listed
+ *                nowhere under this rule. */
+int hvrt_set_overlap_test(hvrt_ctx* ctx, int mode);
 int hvrt_get_timings(const hvrt_ctx* ctx, hvrt_timings* out);
 /* Durations of the last asynchronous traversals (hvrt_render_part_device, hvrt_render_batch_part_device, the noalloc
  * form), for callers that queue several launches and wait once: waits for the stream, then writes up to max_entries

@@ -88,12 +88,59 @@ static inline void tri_range(const float* t, const int n[3], const float mn[3], 
     }
 }
 
+/* Triangle / box overlap by separating axes (Akenine-Moller 2001), for the SAT option of the voxelizer
+ * (hvrt_set_overlap_test(ctx, 1)).  NOT in the reference: GeometryUtils.h:19 declares triangleIntersectsBox and no
+ * file defines it, so nothing pins this -- parity unpinned; it restates the published test for the voxel grown by
+ * 2^-10 of its half size, in plain fp32 operations in the order libhvrt uses, and the tests compare the two CSRs. */
+static inline float abs1(float x) { return x < 0.0f ? -x : x; }
+static inline int separated(float p0, float p1, float p2, float r) {
+    const float lo = min2(min2(p0, p1), p2), hi = max2(max2(p0, p1), p2);
+    return lo > r || hi < -r;
+}
+static inline int edge_separates(const float e[3], const float h[3], const float a[3], const float b[3], const float d[3]) {
+    const float fx = abs1(e[0]), fy = abs1(e[1]), fz = abs1(e[2]);
+    if (separated(e[2] * a[1] - e[1] * a[2], e[2] * b[1] - e[1] * b[2], e[2] * d[1] - e[1] * d[2], h[1] * fz + h[2] * fy)) return 1;
+    if (separated(e[0] * a[2] - e[2] * a[0], e[0] * b[2] - e[2] * b[0], e[0] * d[2] - e[2] * d[0], h[0] * fz + h[2] * fx)) return 1;
+    if (separated(e[1] * a[0] - e[0] * a[1], e[1] * b[0] - e[0] * b[1], e[1] * d[0] - e[0] * d[1], h[0] * fy + h[1] * fx)) return 1;
+    return 0;
+}
+int orc_triangle_box_overlap(const float* t, const float mn[3], const float vs[3], int ix, int iy, int iz) {
+    const float GROW = 1.0009765625f;
+    const int idx[3] = { ix, iy, iz };
+    float h[3], a[3], b[3], d[3], e0[3], e1[3], e2[3];
+    for (int k = 0; k < 3; ++k) {
+        const float c = mn[k] + ((float)idx[k] + 0.5f) * vs[k];
+        h[k] = (0.5f * vs[k]) * GROW;
+        a[k] = t[k] - c; b[k] = t[3 + k] - c; d[k] = t[6 + k] - c;
+    }
+    for (int k = 0; k < 3; ++k) if (separated(a[k], b[k], d[k], h[k])) return 0;
+    for (int k = 0; k < 3; ++k) { e0[k] = b[k] - a[k]; e1[k] = d[k] - b[k]; e2[k] = a[k] - d[k]; }
+    if (edge_separates(e0, h, a, b, d) || edge_separates(e1, h, a, b, d) || edge_separates(e2, h, a, b, d)) return 0;
+    const float nx = e0[1] * e1[2] - e0[2] * e1[1], ny = e0[2] * e1[0] - e0[0] * e1[2], nz = e0[0] * e1[1] - e0[1] * e1[0];
+    const float dist = (nx * a[0] + ny * a[1]) + nz * a[2];
+    const float r = (h[0] * abs1(nx) + h[1] * abs1(ny)) + h[2] * abs1(nz);
+    if (dist > r || dist < -r) return 0;
+    return 1;
+}
+
 /* SceneCreator.cpp:197-281.  The reference appends t (ascending) to a vector per voxel and then
  * flattens the vectors in flat order ix + nx*(iy + ny*iz); a count / exclusive-scan / fill in
  * ascending t produces the same two arrays. */
+static uint64_t voxelize(const float* tris, uint32_t T, int nx, int ny, int nz, const float mn[3], const float vs[3],
+                         uint32_t* offsets, uint32_t* indices, int sat);
 uint64_t orc_voxelize(const float* tris, uint32_t T, int nx, int ny, int nz,
                       const float mn[3], const float vs[3],
                       uint32_t* offsets, uint32_t* indices) {
+    return voxelize(tris, T, nx, ny, nz, mn, vs, offsets, indices, 0);
+}
+/* The SAT option (not the reference's rule): a voxel of the range keeps the triangle only if the two overlap. */
+uint64_t orc_voxelize_sat(const float* tris, uint32_t T, int nx, int ny, int nz,
+                          const float mn[3], const float vs[3],
+                          uint32_t* offsets, uint32_t* indices) {
+    return voxelize(tris, T, nx, ny, nz, mn, vs, offsets, indices, 1);
+}
+static uint64_t voxelize(const float* tris, uint32_t T, int nx, int ny, int nz, const float mn[3], const float vs[3],
+                         uint32_t* offsets, uint32_t* indices, int sat) {
     const int n[3] = { nx, ny, nz };
     const uint64_t nvox = (uint64_t)nx * ny * nz;
     memset(offsets, 0, (nvox + 1) * sizeof(uint32_t));
@@ -103,7 +150,8 @@ uint64_t orc_voxelize(const float* tris, uint32_t T, int nx, int ny, int nz,
         for (int iz = lo[2]; iz <= hi[2]; ++iz)
             for (int iy = lo[1]; iy <= hi[1]; ++iy)
                 for (int ix = lo[0]; ix <= hi[0]; ++ix)
-                    offsets[1 + (uint64_t)ix + (uint64_t)nx * ((uint64_t)iy + (uint64_t)ny * iz)]++;
+                    if (!sat || orc_triangle_box_overlap(tris + 12ull * t, mn, vs, ix, iy, iz))
+                        offsets[1 + (uint64_t)ix + (uint64_t)nx * ((uint64_t)iy + (uint64_t)ny * iz)]++;
     }
     /* offsets[v+1] holds count(v); turn it into start(v) stored at offsets[v+1] temporarily. */
     uint64_t run = 0;
@@ -115,6 +163,7 @@ uint64_t orc_voxelize(const float* tris, uint32_t T, int nx, int ny, int nz,
             for (int iz = lo[2]; iz <= hi[2]; ++iz)
                 for (int iy = lo[1]; iy <= hi[1]; ++iy)
                     for (int ix = lo[0]; ix <= hi[0]; ++ix) {
+                        if (sat && !orc_triangle_box_overlap(tris + 12ull * t, mn, vs, ix, iy, iz)) continue;
                         uint64_t f = (uint64_t)ix + (uint64_t)nx * ((uint64_t)iy + (uint64_t)ny * iz);
                         indices[offsets[f + 1]++] = t;
                     }

@@ -84,6 +84,11 @@ float orc_voxel_size(const float mn[3], const float mx[3], int nx, int ny, int n
 uint64_t orc_voxelize(const float* tris, uint32_t n_tris, int nx, int ny, int nz,
                       const float mn[3], const float vs[3],
                       uint32_t* offsets, uint32_t* indices);
+/* The separating-axis option of the voxelizer (hvrt_set_overlap_test(ctx, 1)).  NOT the reference's rule and pinned by
+ * nothing in it (GeometryUtils.h:19 declares triangleIntersectsBox, no file defines it): parity unpinned. */
+uint64_t orc_voxelize_sat(const float* tris, uint32_t n_tris, int nx, int ny, int nz,
+                          const float mn[3], const float vs[3], uint32_t* offsets, uint32_t* indices);
+int orc_triangle_box_overlap(const float* tri, const float mn[3], const float vs[3], int ix, int iy, int iz);
 
 /* OctreeLikeRayTracer.cpp:342-359, the loop-invariant head of generateRay. */
 void orc_camera_frame_make(const float pos[3], const float look_at[3], const float up[3],

@@ -25,7 +25,7 @@ SYMBOLS = [
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc", "hvrt_last_hit_count",
-    "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count", "hvrt_render_history",
+    "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count", "hvrt_render_history", "hvrt_set_overlap_test",
     "hvrt_group_create", "hvrt_group_destroy", "hvrt_group_last_error", "hvrt_group_size", "hvrt_group_transport",
     "hvrt_group_member", "hvrt_group_replicate_scene", "hvrt_group_render",
 ]
@@ -126,6 +126,7 @@ def load_library() -> C.CDLL:
     lib.hvrt_group_replicate_scene.argtypes = [vp]
     lib.hvrt_group_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp]
     lib.hvrt_set_deferred_accel.argtypes = [vp, C.c_int]
+    lib.hvrt_set_overlap_test.argtypes = [vp, C.c_int]
     lib.hvrt_finish_accel.argtypes = [vp]
     lib.hvrt_render_batch_part_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
                                                   C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
@@ -359,6 +360,11 @@ class Context:
         if got < 0:
             self._ck(-1)
         return [float(buf[i]) for i in range(got)]
+
+    def set_overlap_test(self, mode: int):
+        """0 = every voxel of a triangle's bounding-box range lists it (the reference's rule, default); 1 = those it overlaps
+        (separating-axis test).  For later build_grid calls."""
+        self._ck(self._lib.hvrt_set_overlap_test(self._h, mode))
 
     def set_mode(self, mode: int):
         """0 = the reference's traversal (default), 1 = nearest-hit mode."""

@@ -84,6 +84,9 @@ struct hvrt_ctx {
     bool defer_accel = false;      // hvrt_set_deferred_accel
     bool accel_pending = false;    // the CSR is final, the derived data is not built yet
     bool accel_built_here = false; // whether the pending data belongs to a grid built here (ranges / vox_of usable)
+    int overlap_mode = 0;          // hvrt_set_overlap_test: 0 = the reference's bounding-box rule, 1 = separating axes (later builds)
+    bool lists_follow_ranges = false;   // the grid in place lists a triangle in EVERY voxel of its range (built here, box rule):
+                                        // "also listed in that neighbour" is then a compare with the range, not a search
     float* bounds_v = nullptr; uint64_t* bounds_i = nullptr; float* bounds_out = nullptr;
 
     // render scratch
@@ -332,7 +335,7 @@ int make_ref_records_inner(hvrt_ctx* c, hipStream_t s, bool validate, const RefC
     // last entry stays inside the array
     const uint64_t n_alloc = rc.live ? rc.cap : rc.n;
     if (int r = ensure<uint32_t>(c, c->face_bits, c->face_bits_capacity, 6 * face_words_for(n_alloc))) return r;
-    HIP_TRY(c, launch_face_bits(c->indices, rc, offsets_of(c), c->g, c->n_tris, validate ? nullptr : c->ranges,
+    HIP_TRY(c, launch_face_bits(c->indices, rc, offsets_of(c), c->g, c->n_tris, (validate || !c->lists_follow_ranges) ? nullptr : c->ranges,
                                 validate ? nullptr : c->vox_of, c->face_bits, s));
     if (n_alloc == 0) return HVRT_OK;
     const bool want = c->inline_records;
@@ -464,6 +467,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if (const char* v = getenv("HVRT_BUILD_REUSE")) c->reuse_arrays = atoi(v) != 0;
     if (const char* v = getenv("HVRT_BUILD_NARROW")) c->narrow_counters = atoi(v) != 0;
     if (const char* v = getenv("HVRT_SPLIT_WAIT")) c->wait_for_split = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_OVERLAP")) c->overlap_mode = strcmp(v, "sat") == 0 ? 1 : 0;      // the default of hvrt_set_overlap_test
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_ABORT_US")) {
@@ -573,6 +577,13 @@ int hvrt_synchronize(hvrt_ctx* c) {
     if (int r = bind(c)) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->render_pending) { c->tm.render_ms = ms_between(c->ev[6], c->ev[7]); c->render_pending = false; }
+    return HVRT_OK;
+}
+
+int hvrt_set_overlap_test(hvrt_ctx* c, int mode) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (mode != 0 && mode != 1) return fail(c, HVRT_ERR_INVALID, "set_overlap_test: mode %d is neither 0 (bounding box, the reference's rule) nor 1 (separating axes)", mode);
+    c->overlap_mode = mode;
     return HVRT_OK;
 }
 
@@ -687,6 +698,8 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     c->has_grid = false;
     c->cost_valid = false;
     c->accel_pending = false;
+    const bool sat = c->overlap_mode == 1;
+    c->lists_follow_ranges = !sat;          // (read when the derived data is built, inside this call or deferred)
     (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
     set_grid_params(c, nx, ny, nz, mn, mx, vs);
     const uint64_t nvox = c->g.nvox, npad = padded_vox(nvox), n_chunks = npad / SCAN_CHUNK;
@@ -716,7 +729,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
             HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
         }
         HIP_TRY(c, hipMemsetAsync(c->stats, 0, (STATS_STATUS + n_chunks) * sizeof(uint64_t), s));
-        HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, narrow ? c->cnt16 : cnt_of(c), narrow, c->stats + STATS_VOL_SUMS, c->ranges, s));
+        HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, narrow ? c->cnt16 : cnt_of(c), narrow, c->stats + STATS_VOL_SUMS, c->ranges, sat, s));
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
         HIP_TRY(c, launch_scan(cnt_of(c), narrow ? c->cnt16 : nullptr, c->stats + STATS_VOL_SUMS, n_chunks, status_aux, c->stats, c->occ_bits, s));
         c->occ_bits_valid = true;
@@ -769,7 +782,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
         uint32_t* unsorted = c->fill_scratch;
         uint32_t* vox_of = c->fill_scratch + rc.cap;
         HIP_TRY(c, hipEventRecord(c->ev[3], s));
-        HIP_TRY(c, launch_fill(c->ranges, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, rc, s));
+        HIP_TRY(c, launch_fill(c->ranges, c->tri_aos, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, rc, sat, s));
         HIP_TRY(c, hipEventRecord(c->ev[4], s));
         if (!c->defer_accel && !c->dist_in_flight) if (int r = fork_distance_field(c, s)) return r;     // offsets are final from here on
         HIP_TRY(c, launch_sort(offsets_of(c), unsorted, vox_of, rc, c->indices, c->long_queue, c->long_queue_capacity, c->stats, s));
@@ -793,7 +806,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
     // scan left it).  Otherwise wait for the count and size them.
     uint64_t total = 0;
     for (;;) {
-        const bool narrow = c->narrow_counters;
+        const bool narrow = c->narrow_counters && !sat;       // (the 16-bit counters' cross-check is the sum of the range volumes)
         (void)join_distance_field(c, s);        // (second round only: the first one's field is being recomputed)
         note("queueing count + scan");
         if (int r = front(narrow)) return r;
@@ -873,6 +886,7 @@ static int adopt_csr(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], con
     c->max_list = (uint32_t)h_stats[2];
     c->accel_pending = c->defer_accel;
     c->accel_built_here = false;
+    c->lists_follow_ranges = false;
     c->vox_of = nullptr;
     if (!c->defer_accel) {
         const RefCount rc = { nullptr, n_refs, n_refs };

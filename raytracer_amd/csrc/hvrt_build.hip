@@ -56,6 +56,56 @@ __device__ __forceinline__ bool ref_count(const RefCount& r, uint64_t& n) {
 __device__ __forceinline__ uint64_t face_words_of(uint64_t n_refs) { return (n_refs + 63) / 64 * 2 + 2; }
 
 // ------------------------------------------------------------------------------------------
+// triangle / box overlap by separating axes (hvrt_set_overlap_test(ctx, 1); an extension)
+// ------------------------------------------------------------------------------------------
+// The reference lists a triangle in every voxel of its bounding box (SceneCreator.cpp:197-281; triangleIntersectsBox
+// is declared in GeometryUtils.h:19 and never defined).  With the SAT rule a voxel of that range keeps the triangle
+// only if the two really overlap: Akenine-Moller's test -- the box's three normals, the triangle's normal, the nine
+// products of an edge with a coordinate axis.  The box is the voxel grown by 2^-10 of its half size, so that rounding
+// can add a voxel to a list but not drop one; every compare that involves a NaN is false, i.e. "not separated".
+// Plain fp32 operations in a fixed order (no contraction), so that a CPU restatement gives the same lists bit for bit.
+// Geometry outside the grid overlaps no voxel: where the reference's clamped indices put it into the border voxels
+// (a non-cubic grid under a round mesh), this rule lists it nowhere.
+struct Tri9 { float ax, ay, az, bx, by, bz, cx, cy, cz; };
+__device__ __forceinline__ float abs1(float x) { return x < 0.0f ? -x : x; }
+__device__ __forceinline__ bool separated(float p0, float p1, float p2, float r) {
+    const float lo = min2(min2(p0, p1), p2), hi = max2(max2(p0, p1), p2);
+    return lo > r || hi < -r;
+}
+__device__ __forceinline__ bool edge_separates(float ex, float ey, float ez, float hx, float hy, float hz,
+                                               float ax, float ay, float az, float bx, float by, float bz,
+                                               float cx, float cy, float cz) {
+    const float fx = abs1(ex), fy = abs1(ey), fz = abs1(ez);
+    // e x (1,0,0) = (0, ez, -ey) up to sign: p = ez * y - ey * z
+    if (separated(ez * ay - ey * az, ez * by - ey * bz, ez * cy - ey * cz, hy * fz + hz * fy)) return true;
+    // e x (0,1,0): p = ex * z - ez * x
+    if (separated(ex * az - ez * ax, ex * bz - ez * bx, ex * cz - ez * cx, hx * fz + hz * fx)) return true;
+    // e x (0,0,1): p = ey * x - ex * y
+    if (separated(ey * ax - ex * ay, ey * bx - ex * by, ey * cx - ex * cy, hx * fy + hy * fx)) return true;
+    return false;
+}
+__device__ __forceinline__ bool tri_box_overlap(const GridParams& g, const Tri9& t, int ix, int iy, int iz) {
+    const float GROW = 1.0009765625f;       // 1 + 2^-10
+    const float cx = g.mnx + ((float)ix + 0.5f) * g.vsx, cy = g.mny + ((float)iy + 0.5f) * g.vsy, cz = g.mnz + ((float)iz + 0.5f) * g.vsz;
+    const float hx = (0.5f * g.vsx) * GROW, hy = (0.5f * g.vsy) * GROW, hz = (0.5f * g.vsz) * GROW;
+    const float ax = t.ax - cx, ay = t.ay - cy, az = t.az - cz;
+    const float bx = t.bx - cx, by = t.by - cy, bz = t.bz - cz;
+    const float dx = t.cx - cx, dy = t.cy - cy, dz = t.cz - cz;
+    if (separated(ax, bx, dx, hx) || separated(ay, by, dy, hy) || separated(az, bz, dz, hz)) return false;
+    const float e0x = bx - ax, e0y = by - ay, e0z = bz - az;
+    const float e1x = dx - bx, e1y = dy - by, e1z = dz - bz;
+    const float e2x = ax - dx, e2y = ay - dy, e2z = az - dz;
+    if (edge_separates(e0x, e0y, e0z, hx, hy, hz, ax, ay, az, bx, by, bz, dx, dy, dz)) return false;
+    if (edge_separates(e1x, e1y, e1z, hx, hy, hz, ax, ay, az, bx, by, bz, dx, dy, dz)) return false;
+    if (edge_separates(e2x, e2y, e2z, hx, hy, hz, ax, ay, az, bx, by, bz, dx, dy, dz)) return false;
+    const float nx = e0y * e1z - e0z * e1y, ny = e0z * e1x - e0x * e1z, nz = e0x * e1y - e0y * e1x;
+    const float d = (nx * ax + ny * ay) + nz * az;
+    const float r = (hx * abs1(nx) + hy * abs1(ny)) + hz * abs1(nz);
+    if (d > r || d < -r) return false;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
 // records: v0, e1, e2, normal
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_prepare_records(const float4* __restrict__ aos,
@@ -141,9 +191,9 @@ __device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uin
     }
 }
 
-template <int MODE>
+template <int MODE, bool SAT = false>
 __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, uint32_t t,
-                                           bool valid, int lx, int ly, int lz, int hx, int hy, int hz) {
+                                           bool valid, int lx, int ly, int lz, int hx, int hy, int hz, const Tri9& tri = Tri9()) {
     const uint32_t dx = valid ? (uint32_t)(hx - lx + 1) : 0u;
     const uint32_t dy = valid ? (uint32_t)(hy - ly + 1) : 0u;
     const uint32_t dz = valid ? (uint32_t)(hz - lz + 1) : 0u;
@@ -156,7 +206,8 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
         int ix = lx, iy = ly, iz = lz;
         bool act = small;
         while (__ballot(act)) {
-            touch_runs<MODE>(cnt, indices, vox_of, act, (uint32_t)flat_index(g, ix, iy, iz), t);
+            const bool listed = act && (!SAT || tri_box_overlap(g, tri, ix, iy, iz));
+            touch_runs<MODE>(cnt, indices, vox_of, listed, (uint32_t)flat_index(g, ix, iy, iz), t);
             if (act) {
                 if (++ix > hx) { ix = lx; if (++iy > hy) { iy = ly; if (++iz > hz) act = false; } }
             }
@@ -171,12 +222,19 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
         const int blx = __shfl(lx, src), bly = __shfl(ly, src), blz = __shfl(lz, src);
         const uint32_t bdx = __shfl(dx, src), bdy = __shfl(dy, src), bdz = __shfl(dz, src);
         const uint32_t bt = __shfl(t, src);
+        Tri9 btri = tri;
+        if (SAT) {
+            btri.ax = __shfl(tri.ax, src); btri.ay = __shfl(tri.ay, src); btri.az = __shfl(tri.az, src);
+            btri.bx = __shfl(tri.bx, src); btri.by = __shfl(tri.by, src); btri.bz = __shfl(tri.bz, src);
+            btri.cx = __shfl(tri.cx, src); btri.cy = __shfl(tri.cy, src); btri.cz = __shfl(tri.cz, src);
+        }
         const uint64_t bvol = (uint64_t)bdx * bdy * bdz;
         const uint64_t plane = (uint64_t)bdx * bdy;
         for (uint64_t i = lane; i < bvol; i += 64) {
             const uint32_t iz = (uint32_t)(i / plane);
             const uint32_t r = (uint32_t)(i - (uint64_t)iz * plane);
             const uint32_t iy = r / bdx, ix = r - iy * bdx;
+            if (SAT && !tri_box_overlap(g, btri, blx + (int)ix, bly + (int)iy, blz + (int)iz)) continue;
             touch<MODE>(cnt, indices, vox_of, flat_index(g, blx + (int)ix, bly + (int)iy, blz + (int)iz), bt);
         }
     }
@@ -187,15 +245,17 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v);
 // vol_sums (COUNT16 only): 64 words a cache line apart; every workgroup adds the number of references its triangles
 // make (the sum of their range volumes, exact in 64 bits) to one of them -- the independent total that tells a
 // carried 16-bit counter from a sound one
-template <int MODE>
+template <int MODE, bool SAT = false>
 __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, uint32_t T, GridParams g,
                                                uint32_t* __restrict__ cnt, uint32_t* __restrict__ ranges,
                                                uint64_t* __restrict__ vol_sums) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool valid = t < T;
     int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
+    Tri9 tri = {};
     if (valid) {
         float4 a = aos[3ull * t], b = aos[3ull * t + 1], c = aos[3ull * t + 2];
+        if (SAT) tri = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x };
         // computeTriangleMinMax, GeometryUtils.cpp:43-51
         float mnx = min2(min2(a.x, a.w), b.z), mny = min2(min2(a.y, b.x), b.w), mnz = min2(min2(a.z, b.y), c.x);
         float mxx = max2(max2(a.x, a.w), b.z), mxy = max2(max2(a.y, b.x), b.w), mxz = max2(max2(a.z, b.y), c.x);
@@ -222,10 +282,11 @@ __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, u
             if (all) atomicAdd((unsigned long long*)&vol_sums[16u * (blockIdx.x & 63u)], (unsigned long long)all);
         }
     }
-    walk_range<MODE>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz);
+    walk_range<MODE, SAT>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz, tri);
 }
 
-__global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ ranges, uint32_t T, GridParams g,
+template <bool SAT>
+__global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ ranges, const float4* __restrict__ aos, uint32_t T, GridParams g,
                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ indices,
                                               uint32_t* __restrict__ vox_of, RefCount rc) {
     uint64_t n_refs;
@@ -240,7 +301,12 @@ __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ range
         lz = (int)(rz & 0xFFFFu); hz = (int)(rz >> 16);
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
-    walk_range<FILL>(g, cnt, indices, vox_of, t, nonempty, lx, ly, lz, hx, hy, hz);
+    Tri9 tri = {};
+    if (SAT && valid) {
+        const float4 a = aos[3ull * t], b = aos[3ull * t + 1], c = aos[3ull * t + 2];
+        tri = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x };
+    }
+    walk_range<FILL, SAT>(g, cnt, indices, vox_of, t, nonempty, lx, ly, lz, hx, hy, hz, tri);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1127,9 +1193,11 @@ hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_
 }
 
 hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, bool narrow, uint64_t* vol_sums,
-                        uint32_t* ranges, hipStream_t s) {
+                        uint32_t* ranges, bool sat, hipStream_t s) {
     if (T == 0) return hipSuccess;
-    if (narrow) k_count<COUNT16><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, vol_sums);
+    if (sat && narrow) return hipErrorInvalidValue;       // (the 16-bit counters' cross-check is the sum of the range volumes)
+    if (sat) k_count<COUNT32, true><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, nullptr);
+    else if (narrow) k_count<COUNT16><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, vol_sums);
     else k_count<COUNT32><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, nullptr);
     return hipGetLastError();
 }
@@ -1145,10 +1213,11 @@ hipError_t launch_scan(uint32_t* cnt, const uint32_t* cnt16, const uint64_t* vol
     return hipGetLastError();
 }
 
-hipError_t launch_fill(const uint32_t* ranges, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* indices,
-                       uint32_t* vox_of, const RefCount& rc, hipStream_t s) {
+hipError_t launch_fill(const uint32_t* ranges, const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* indices,
+                       uint32_t* vox_of, const RefCount& rc, bool sat, hipStream_t s) {
     if (T == 0) return hipSuccess;
-    k_fill<<<(T + 255) / 256, 256, 0, s>>>(ranges, T, g, cnt, indices, vox_of, rc);
+    if (sat) k_fill<true><<<(T + 255) / 256, 256, 0, s>>>(ranges, (const float4*)tri_aos, T, g, cnt, indices, vox_of, rc);
+    else k_fill<false><<<(T + 255) / 256, 256, 0, s>>>(ranges, nullptr, T, g, cnt, indices, vox_of, rc);
     return hipGetLastError();
 }
 

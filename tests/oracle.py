@@ -49,6 +49,8 @@ def lib() -> C.CDLL:
         l = C.CDLL(LIB)
         l.orc_voxel_size.restype = C.c_float
         l.orc_voxelize.restype = C.c_uint64
+        l.orc_voxelize_sat.restype = C.c_uint64
+        l.orc_triangle_box_overlap.restype = C.c_int
         l.orc_ray_triangle.restype = C.c_int
         l.orc_ray_box.restype = C.c_int
         _lib = l
@@ -93,15 +95,17 @@ def voxel_size(mn, mx, nx, ny, nz) -> np.float32:
     return np.float32(lib().orc_voxel_size(_p(mn), _p(mx), nx, ny, nz))
 
 
-def voxelize(tri_aos: np.ndarray, nx, ny, nz, mn, vs3):
+def voxelize(tri_aos: np.ndarray, nx, ny, nz, mn, vs3, sat=False):
+    """sat: the separating-axis option (not the reference's rule; orc_voxelize_sat)."""
     t = np.ascontiguousarray(tri_aos, np.float32).reshape(-1, 12)
     mn = np.ascontiguousarray(mn, np.float32)
     vs3 = np.ascontiguousarray(np.broadcast_to(np.asarray(vs3, np.float32), (3,)))
     nvox = nx * ny * nz
     off = np.zeros(nvox + 1, np.uint32)
-    n = lib().orc_voxelize(_p(t), C.c_uint32(t.shape[0]), nx, ny, nz, _p(mn), _p(vs3), _p(off), None)
+    fn = lib().orc_voxelize_sat if sat else lib().orc_voxelize
+    n = fn(_p(t), C.c_uint32(t.shape[0]), nx, ny, nz, _p(mn), _p(vs3), _p(off), None)
     idx = np.zeros(n, np.uint32)
-    n2 = lib().orc_voxelize(_p(t), C.c_uint32(t.shape[0]), nx, ny, nz, _p(mn), _p(vs3), _p(off), _p(idx))
+    n2 = fn(_p(t), C.c_uint32(t.shape[0]), nx, ny, nz, _p(mn), _p(vs3), _p(off), _p(idx))
     assert n == n2 == int(off[-1])
     return off, idx
 
