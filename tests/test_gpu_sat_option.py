@@ -143,3 +143,20 @@ def test_overlap_rule_is_per_context_and_checked(sat_ctx, ctx):
     ooff, oidx = oracle.voxelize(tris, 16, 16, 16, mn, vs)
     off, idx = sat_ctx.get_csr()
     assert a.n_refs < b.n_refs == oidx.size and np.array_equal(off, ooff) and np.array_equal(idx, oidx)
+
+
+def test_sat_grid_with_deferred_derived_data(sat_ctx):
+    """hvrt_set_deferred_accel: the face bits are then made at the first render, from the lists (not from the ranges)."""
+    tris = np.ascontiguousarray(meshgen.cube_sphere(24), np.float32)
+    dims = (32, 32, 32)
+    sat_ctx.set_deferred_accel(True)
+    try:
+        info, mn, mx, vs = _build(sat_ctx, tris, dims)
+        off, idx = sat_ctx.get_csr()
+        sc = oracle.OracleScene(tris, *dims, mn, vs, off, idx, mx=mx)
+        fr = capi.make_camera_frame(*capi.default_camera(mn, mx, "side"))
+        exp = sc.render(fr, 240, 180, threads=8)
+        rgb, hit, t, cnt = sat_ctx.render(fr, 240, 180)
+        assert np.array_equal(hit, exp[1]) and np.array_equal(t.view(np.uint32), exp[2].view(np.uint32)) and np.array_equal(cnt, exp[3])
+    finally:
+        sat_ctx.set_deferred_accel(False)
