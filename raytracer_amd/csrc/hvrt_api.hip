@@ -84,6 +84,7 @@ struct hvrt_ctx {
     bool defer_accel = false;      // hvrt_set_deferred_accel
     bool accel_pending = false;    // the CSR is final, the derived data is not built yet
     bool accel_built_here = false; // whether the pending data belongs to a grid built here (ranges / vox_of usable)
+    uint32_t* sat_mask = nullptr; uint64_t sat_mask_capacity = 0;    // SAT builds: per triangle, which voxels of a small range keep it
     int overlap_mode = 0;          // hvrt_set_overlap_test: 0 = the reference's bounding-box rule, 1 = separating axes (later builds)
     bool lists_follow_ranges = false;   // the grid in place lists a triangle in EVERY voxel of its range (built here, box rule):
                                         // "also listed in that neighbour" is then a compare with the range, not a search
@@ -530,7 +531,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->df_stream) (void)hipStreamSynchronize(c->df_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->cnt16, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
+    void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->sat_mask, c->cnt16, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
                      c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -706,6 +707,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
 
     if (int r = ensure<uint32_t>(c, c->cnt_base, c->cnt_capacity, npad + 8)) return r;
     if (int r = ensure<uint32_t>(c, c->ranges, c->ranges_capacity, (uint64_t)c->n_tris * 3)) return r;
+    if (sat) if (int r = ensure<uint32_t>(c, c->sat_mask, c->sat_mask_capacity, (uint64_t)c->n_tris)) return r;
     if (int r = ensure<uint32_t>(c, c->occ_bits, c->occ_bits_capacity, npad / 32)) return r;
     if (c->stats_capacity < STATS_STATUS + 2 * n_chunks) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));            // a render may still be reading nothing of it, but be sure
@@ -729,7 +731,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
             HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
         }
         HIP_TRY(c, hipMemsetAsync(c->stats, 0, (STATS_STATUS + n_chunks) * sizeof(uint64_t), s));
-        HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, narrow ? c->cnt16 : cnt_of(c), narrow, c->stats + STATS_VOL_SUMS, c->ranges, sat, s));
+        HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, narrow ? c->cnt16 : cnt_of(c), narrow, c->stats + STATS_VOL_SUMS, c->ranges, sat ? c->sat_mask : nullptr, s));
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
         HIP_TRY(c, launch_scan(cnt_of(c), narrow ? c->cnt16 : nullptr, c->stats + STATS_VOL_SUMS, n_chunks, status_aux, c->stats, c->occ_bits, s));
         c->occ_bits_valid = true;
@@ -782,7 +784,7 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
         uint32_t* unsorted = c->fill_scratch;
         uint32_t* vox_of = c->fill_scratch + rc.cap;
         HIP_TRY(c, hipEventRecord(c->ev[3], s));
-        HIP_TRY(c, launch_fill(c->ranges, c->tri_aos, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, rc, sat, s));
+        HIP_TRY(c, launch_fill(c->ranges, c->tri_aos, c->n_tris, c->g, cnt_of(c), unsorted, vox_of, rc, sat ? c->sat_mask : nullptr, s));
         HIP_TRY(c, hipEventRecord(c->ev[4], s));
         if (!c->defer_accel && !c->dist_in_flight) if (int r = fork_distance_field(c, s)) return r;     // offsets are final from here on
         HIP_TRY(c, launch_sort(offsets_of(c), unsorted, vox_of, rc, c->indices, c->long_queue, c->long_queue_capacity, c->stats, s));

@@ -191,9 +191,11 @@ __device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uin
     }
 }
 
+// SAT: `mask` carries the verdicts on a small range (bit k: the k-th voxel of the walk keeps the triangle) from the count
+// pass, which works them out, to the scatter, which then needs neither the triangle nor the test again.
 template <int MODE, bool SAT = false>
 __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, uint32_t* indices, uint32_t* vox_of, uint32_t t,
-                                           bool valid, int lx, int ly, int lz, int hx, int hy, int hz, const Tri9& tri = Tri9()) {
+                                           bool valid, int lx, int ly, int lz, int hx, int hy, int hz, const Tri9& tri, uint32_t& mask) {
     const uint32_t dx = valid ? (uint32_t)(hx - lx + 1) : 0u;
     const uint32_t dy = valid ? (uint32_t)(hy - ly + 1) : 0u;
     const uint32_t dz = valid ? (uint32_t)(hz - lz + 1) : 0u;
@@ -205,8 +207,14 @@ __device__ __forceinline__ void walk_range(const GridParams& g, uint32_t* cnt, u
         const bool small = valid && !big;
         int ix = lx, iy = ly, iz = lz;
         bool act = small;
+        uint32_t step = 0;          // < SMALL_VOL = 32 while act
         while (__ballot(act)) {
-            const bool listed = act && (!SAT || tri_box_overlap(g, tri, ix, iy, iz));
+            bool listed = act;
+            if (SAT && act) {
+                if (MODE == FILL) listed = (mask >> step) & 1u;
+                else { listed = tri_box_overlap(g, tri, ix, iy, iz); mask |= (listed ? 1u : 0u) << step; }
+            }
+            ++step;
             touch_runs<MODE>(cnt, indices, vox_of, listed, (uint32_t)flat_index(g, ix, iy, iz), t);
             if (act) {
                 if (++ix > hx) { ix = lx; if (++iy > hy) { iy = ly; if (++iz > hz) act = false; } }
@@ -248,7 +256,7 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v);
 template <int MODE, bool SAT = false>
 __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, uint32_t T, GridParams g,
                                                uint32_t* __restrict__ cnt, uint32_t* __restrict__ ranges,
-                                               uint64_t* __restrict__ vol_sums) {
+                                               uint64_t* __restrict__ vol_sums, uint32_t* __restrict__ sat_mask) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const bool valid = t < T;
     int lx = 0, ly = 0, lz = 0, hx = -1, hy = -1, hz = -1;
@@ -282,13 +290,15 @@ __global__ __launch_bounds__(256) void k_count(const float4* __restrict__ aos, u
             if (all) atomicAdd((unsigned long long*)&vol_sums[16u * (blockIdx.x & 63u)], (unsigned long long)all);
         }
     }
-    walk_range<MODE, SAT>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz, tri);
+    uint32_t mask = 0;
+    walk_range<MODE, SAT>(g, cnt, nullptr, nullptr, t, nonempty, lx, ly, lz, hx, hy, hz, tri, mask);
+    if (SAT && valid) sat_mask[t] = mask;
 }
 
 template <bool SAT>
 __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ ranges, const float4* __restrict__ aos, uint32_t T, GridParams g,
                                               uint32_t* __restrict__ cnt, uint32_t* __restrict__ indices,
-                                              uint32_t* __restrict__ vox_of, RefCount rc) {
+                                              uint32_t* __restrict__ vox_of, RefCount rc, const uint32_t* __restrict__ sat_mask) {
     uint64_t n_refs;
     if (!ref_count(rc, n_refs)) return;      // uniform: the arrays are too small for this build, nothing is scattered
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -302,11 +312,17 @@ __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ range
     }
     const bool nonempty = valid && lx <= hx && ly <= hy && lz <= hz;
     Tri9 tri = {};
-    if (SAT && valid) {
-        const float4 a = aos[3ull * t], b = aos[3ull * t + 1], c = aos[3ull * t + 2];
-        tri = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x };
+    uint32_t mask = 0;
+    if (SAT && nonempty) {
+        // a small range brings its verdicts along; a big one (the whole wave walks it) is tested again
+        if ((uint64_t)(hx - lx + 1) * (uint64_t)(hy - ly + 1) * (uint64_t)(hz - lz + 1) > SMALL_VOL) {
+            const float4 a = aos[3ull * t], b = aos[3ull * t + 1], c = aos[3ull * t + 2];
+            tri = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x };
+        } else {
+            mask = sat_mask[t];
+        }
     }
-    walk_range<FILL, SAT>(g, cnt, indices, vox_of, t, nonempty, lx, ly, lz, hx, hy, hz, tri);
+    walk_range<FILL, SAT>(g, cnt, indices, vox_of, t, nonempty, lx, ly, lz, hx, hy, hz, tri, mask);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1193,12 +1209,13 @@ hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_
 }
 
 hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, bool narrow, uint64_t* vol_sums,
-                        uint32_t* ranges, bool sat, hipStream_t s) {
+                        uint32_t* ranges, uint32_t* sat_mask, hipStream_t s) {
     if (T == 0) return hipSuccess;
+    const bool sat = sat_mask != nullptr;
     if (sat && narrow) return hipErrorInvalidValue;       // (the 16-bit counters' cross-check is the sum of the range volumes)
-    if (sat) k_count<COUNT32, true><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, nullptr);
-    else if (narrow) k_count<COUNT16><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, vol_sums);
-    else k_count<COUNT32><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, nullptr);
+    if (sat) k_count<COUNT32, true><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, nullptr, sat_mask);
+    else if (narrow) k_count<COUNT16><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, vol_sums, nullptr);
+    else k_count<COUNT32><<<(T + 255) / 256, 256, 0, s>>>((const float4*)tri_aos, T, g, cnt, ranges, nullptr, nullptr);
     return hipGetLastError();
 }
 
@@ -1214,10 +1231,10 @@ hipError_t launch_scan(uint32_t* cnt, const uint32_t* cnt16, const uint64_t* vol
 }
 
 hipError_t launch_fill(const uint32_t* ranges, const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, uint32_t* indices,
-                       uint32_t* vox_of, const RefCount& rc, bool sat, hipStream_t s) {
+                       uint32_t* vox_of, const RefCount& rc, const uint32_t* sat_mask, hipStream_t s) {
     if (T == 0) return hipSuccess;
-    if (sat) k_fill<true><<<(T + 255) / 256, 256, 0, s>>>(ranges, (const float4*)tri_aos, T, g, cnt, indices, vox_of, rc);
-    else k_fill<false><<<(T + 255) / 256, 256, 0, s>>>(ranges, nullptr, T, g, cnt, indices, vox_of, rc);
+    if (sat_mask) k_fill<true><<<(T + 255) / 256, 256, 0, s>>>(ranges, (const float4*)tri_aos, T, g, cnt, indices, vox_of, rc, sat_mask);
+    else k_fill<false><<<(T + 255) / 256, 256, 0, s>>>(ranges, nullptr, T, g, cnt, indices, vox_of, rc, nullptr);
     return hipGetLastError();
 }
 

@@ -100,9 +100,10 @@ hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_
 //   [1032, 1032 + n)    scan status words, then n aux words (n = chunks of the scan)
 constexpr uint64_t STATS_VOL_SUMS = 8, STATS_STATUS = 8 + 1024;
 // narrow: cnt is the 16-bit counter array (two per word; zero on entry) and vol_sums collects the exact total
-// sat: list a triangle only in the voxels of its range that it overlaps (separating-axis test; 32-bit counters only)
+// sat_mask (n_tris words, or null): list a triangle only in the voxels of its range that it overlaps (separating-axis test;
+// 32-bit counters only); the verdicts on ranges of up to 32 voxels are left there for launch_fill
 hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt, bool narrow,
-                        uint64_t* vol_sums, uint32_t* ranges, bool sat, hipStream_t s);
+                        uint64_t* vol_sums, uint32_t* ranges, uint32_t* sat_mask, hipStream_t s);
 // exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64, the first n_chunks zero on entry.
 // cnt16 == nullptr: in place over cnt.  Otherwise the counters are read from cnt16 and the offsets written to cnt.
 // stats[0] <- total (exact, 64-bit, whatever the 32-bit offsets did), stats[1] += occupied voxels, stats[2] <- longest
@@ -122,8 +123,8 @@ struct RefCount {
     uint64_t cap;
 };
 uint64_t face_words_for(uint64_t n_refs);    // words per bit plane of face_bits (SceneDev::face_words)
-hipError_t launch_fill(const uint32_t* ranges, const float* tri_aos /* read when sat */, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
-                       uint32_t* indices_unsorted, uint32_t* vox_of, const RefCount& rc, bool sat, hipStream_t s);
+hipError_t launch_fill(const uint32_t* ranges, const float* tri_aos /* read for big ranges when sat_mask */, uint32_t n_tris, const GridParams& g, uint32_t* cnt,
+                       uint32_t* indices_unsorted, uint32_t* vox_of, const RefCount& rc, const uint32_t* sat_mask, hipStream_t s);
 hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const uint32_t* vox_of, const RefCount& rc,
                        uint32_t* indices, uint32_t* long_queue, uint64_t long_queue_capacity, uint64_t* stats,
                        hipStream_t s);
