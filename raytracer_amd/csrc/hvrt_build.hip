@@ -328,13 +328,17 @@ __global__ __launch_bounds__(256) void k_fill(const uint32_t* __restrict__ range
 // ------------------------------------------------------------------------------------------
 // scan (wave-level primitives)
 // ------------------------------------------------------------------------------------------
+// Inclusive scan over the 64 lanes (all must be active) in six DPP adds: shifts by 1, 2, 4, 8 inside each row of 16 (a
+// lane without a source adds 0), then lane 15 of row 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3.  The shuffle
+// version was six ds_bpermute round trips with an address, a compare and a select each -- and, eight of them unrolled
+// side by side in k_scan, a good part of that kernel's registers.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(v, d);
-        if (lane >= d) v += o;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);     // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);     // row_bcast:31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
@@ -361,6 +365,9 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
 // raises stats[5] and the build is reported as failed -- the kernel cannot hang.
 constexpr uint64_t ST_AGG = 1ull << 62, ST_PFX = 2ull << 62, ST_VALUE = (1ull << 62) - 1ull;
 constexpr uint32_t ST_SPIN_LIMIT = 1u << 22;
+#ifndef HVRT_SCAN_ATTR
+#define HVRT_SCAN_ATTR
+#endif
 constexpr int SCAN_WAVES = SCAN_CHUNK / 2048;       // 16 waves of 2048 counters each
 // occ_bits (nullable): one bit per voxel, "has a list" -- the counters are in registers here anyway, and the
 // distance field's x pass then reads 1/32 of what the offsets would cost it.
@@ -369,7 +376,7 @@ constexpr int SCAN_WAVES = SCAN_CHUNK / 2048;       // 16 waves of 2048 counters
 // 16-byte load and lane -- rows of 512 -- were slower, 2.12 against 1.70 ms at 1024^3: a lane then stores two
 // neighbouring 16-byte pieces, and a wave's store instruction covers its 2 KiB with gaps.)
 template <bool NARROW>
-__global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cnt4, const uint2* __restrict__ cnt16,
+__global__ __launch_bounds__(SCAN_WAVES * 64) HVRT_SCAN_ATTR void k_scan(uint4* __restrict__ cnt4, const uint2* __restrict__ cnt16,
                                                           uint64_t* __restrict__ status,
                                                           uint64_t* __restrict__ aux, uint64_t* __restrict__ stats,
                                                           uint32_t* __restrict__ occ_bits) {
@@ -380,38 +387,46 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cn
     const uint64_t c = s_chunk;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint4* p = cnt4 + c * (SCAN_CHUNK / 4) + w * 512 + lane;
-    uint4 v[8];
+    // The narrow counters stay packed (two registers per row instead of four) and are unpacked where they are used, twice:
+    // with them unpacked the kernel took 93 registers, ONE 16-wave workgroup fitted a CU, and its four phases -- load,
+    // scan, look back, store -- had nothing to overlap with (1.70 ms at 1024^3 where a plain kernel with the same loads
+    // and stores takes 1.22, scripts/ubench/hbm_rate.hip).
+    uint4 v[NARROW ? 1 : 8];
+    uint2 h[NARROW ? 8 : 1];
     uint32_t excl[8];
     if (NARROW) {
         const uint2* q = cnt16 + c * (SCAN_CHUNK / 4) + w * 512 + lane;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const uint2 h = q[k * 64];
-            v[k] = make_uint4(h.x & 0xFFFFu, h.x >> 16, h.y & 0xFFFFu, h.y >> 16);
-        }
+        for (int k = 0; k < 8; ++k) h[k] = q[k * 64];
     } else {
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = p[k * 64];
     }
+    auto row = [&](int k) -> uint4 {
+        if (NARROW) return make_uint4(h[k].x & 0xFFFFu, h[k].x >> 16, h[k].y & 0xFFFFu, h[k].y >> 16);
+        return v[k];
+    };
     uint32_t carry = 0, occ = 0, mx = 0;
     uint64_t exact = 0;     // my counters added up in 64 bits: the 32-bit sums below wrap beyond 2^32 - 1 references
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const uint32_t tot = v[k].x + v[k].y + v[k].z + v[k].w;
-        exact += (uint64_t)v[k].x + (uint64_t)v[k].y + (uint64_t)v[k].z + (uint64_t)v[k].w;
+        const uint4 r4 = row(k);
+        const uint32_t tot = r4.x + r4.y + r4.z + r4.w;
+        if (NARROW) exact += tot;       // (four 16-bit counters: no wrap)
+        else exact += (uint64_t)r4.x + (uint64_t)r4.y + (uint64_t)r4.z + (uint64_t)r4.w;
         const uint32_t inc = wave_inclusive_scan(tot);
         excl[k] = carry + inc - tot;
         carry += __shfl(inc, 63);
-        occ += (v[k].x > 0) + (v[k].y > 0) + (v[k].z > 0) + (v[k].w > 0);
+        occ += (r4.x > 0) + (r4.y > 0) + (r4.z > 0) + (r4.w > 0);
         if (occ_bits) {
             // my four voxels' bits, then eight lanes' nibbles into one word (lanes 0, 8, 16, ... store)
-            uint32_t bits = (v[k].x > 0 ? 1u : 0u) | (v[k].y > 0 ? 2u : 0u) | (v[k].z > 0 ? 4u : 0u) | (v[k].w > 0 ? 8u : 0u);
+            uint32_t bits = (r4.x > 0 ? 1u : 0u) | (r4.y > 0 ? 2u : 0u) | (r4.z > 0 ? 4u : 0u) | (r4.w > 0 ? 8u : 0u);
             bits |= (uint32_t)__shfl_down((int)bits, 1) << 4;
             bits |= (uint32_t)__shfl_down((int)bits, 2) << 8;
             bits |= (uint32_t)__shfl_down((int)bits, 4) << 16;
             if ((lane & 7) == 0) occ_bits[(c * SCAN_CHUNK + (uint64_t)w * 2048u + (uint64_t)k * 256u) / 32u + (uint32_t)(lane >> 3)] = bits;
         }
-        const uint32_t m = v[k].x > v[k].y ? v[k].x : v[k].y, n = v[k].z > v[k].w ? v[k].z : v[k].w;
+        const uint32_t m = r4.x > r4.y ? r4.x : r4.y, n = r4.z > r4.w ? r4.z : r4.w;
         const uint32_t mm = m > n ? m : n;
         mx = mx > mm ? mx : mm;
     }
@@ -469,11 +484,12 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) void k_scan(uint4* __restrict__ cn
     const uint32_t base = (uint32_t)s_base + s_w[w];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+        const uint4 r4 = row(k);
         uint32_t run = base + excl[k];
         uint4 o;
-        o.x = run; run += v[k].x;
-        o.y = run; run += v[k].y;
-        o.z = run; run += v[k].z;
+        o.x = run; run += r4.x;
+        o.y = run; run += r4.y;
+        o.z = run; run += r4.z;
         o.w = run;
         p[k * 64] = o;
     }

@@ -90,7 +90,10 @@ struct RenderArgs {
 };
 
 // ---- launchers (hvrt_build.hip) ----
-constexpr int SCAN_CHUNK = 32768;  // counters per scan workgroup (1024 threads x 32)
+#ifndef HVRT_SCAN_CHUNK
+#define HVRT_SCAN_CHUNK 32768
+#endif
+constexpr int SCAN_CHUNK = HVRT_SCAN_CHUNK;  // counters per scan workgroup (64 lanes x 32 per wave; 16 waves)
 
 hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_t n_tris, hipStream_t s);
 // Build statistics block (one allocation, zeroed with one memset per build):
