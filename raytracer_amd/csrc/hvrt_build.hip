@@ -352,6 +352,18 @@ __device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
     return v;
 }
 
+// sum / maximum over the 64 lanes (all active), the same six DPP steps; the result is wave-uniform
+__device__ __forceinline__ uint32_t wave_total32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(v), 63); }
+__device__ __forceinline__ uint32_t wave_max32_dpp(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // Exclusive scan of the counters, in place, in ONE pass over the array (chained scan with decoupled look-back):
 // a workgroup takes the next chunk (a ticket, so that every chunk before it has already started), scans its 32768
 // counters in registers, publishes the chunk total, adds up the totals of the chunks before it -- looking back
@@ -416,23 +428,24 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) HVRT_SCAN_ATTR void k_scan(uint4* 
         else exact += (uint64_t)r4.x + (uint64_t)r4.y + (uint64_t)r4.z + (uint64_t)r4.w;
         const uint32_t inc = wave_inclusive_scan(tot);
         excl[k] = carry + inc - tot;
-        carry += __shfl(inc, 63);
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
         occ += (r4.x > 0) + (r4.y > 0) + (r4.z > 0) + (r4.w > 0);
         if (occ_bits) {
             // my four voxels' bits, then eight lanes' nibbles into one word (lanes 0, 8, 16, ... store)
             uint32_t bits = (r4.x > 0 ? 1u : 0u) | (r4.y > 0 ? 2u : 0u) | (r4.z > 0 ? 4u : 0u) | (r4.w > 0 ? 8u : 0u);
-            bits |= (uint32_t)__shfl_down((int)bits, 1) << 4;
-            bits |= (uint32_t)__shfl_down((int)bits, 2) << 8;
-            bits |= (uint32_t)__shfl_down((int)bits, 4) << 16;
+            // (row_shl: lane i reads lane i + 1 / 2 / 4 of its row of 16 -- a storing lane's seven neighbours are in its row)
+            bits |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x101, 0xF, 0xF, false) << 4;
+            bits |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x102, 0xF, 0xF, false) << 8;
+            bits |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bits, 0x104, 0xF, 0xF, false) << 16;
             if ((lane & 7) == 0) occ_bits[(c * SCAN_CHUNK + (uint64_t)w * 2048u + (uint64_t)k * 256u) / 32u + (uint32_t)(lane >> 3)] = bits;
         }
         const uint32_t m = r4.x > r4.y ? r4.x : r4.y, n = r4.z > r4.w ? r4.z : r4.w;
         const uint32_t mm = m > n ? m : n;
         mx = mx > mm ? mx : mm;
     }
-    occ = (uint32_t)wave_sum64(occ);
-    mx = wave_max32(mx);
-    exact = wave_sum64(exact);
+    occ = wave_total32(occ);
+    mx = wave_max32_dpp(mx);
+    exact = NARROW ? (uint64_t)wave_total32((uint32_t)exact) : wave_sum64(exact);      // (narrow: 2048 x 65535 < 2^32)
     if (lane == 0) { s_w[w] = carry; s_occ[w] = occ; s_mx[w] = mx; s_w64[w] = exact; }
     __syncthreads();
     if (w == 0) {
