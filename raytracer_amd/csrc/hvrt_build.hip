@@ -161,7 +161,7 @@ __device__ __forceinline__ void touch_runs(uint32_t* cnt, uint32_t* indices, uin
     // neighbour's, so that a run of lanes walking along x is still ONE atomic (two different voxels of one word
     // would otherwise be two atomics on the same address, which the L2 serialises)
     const uint32_t key = MODE == COUNT16 ? f >> 1 : f;
-    const uint32_t kprev = __shfl_up(key, 1);
+    const uint32_t kprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane - 1's key; lane 0 does not look)
     const bool prev_act = lane > 0 && ((S >> (lane - 1)) & 1ull);
     const unsigned long long H = __ballot(act && (!prev_act || kprev != key));
     // my run's first lane: the highest head at or below me
