@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- primary-ray throughput at 4K on BASELINE.json config 2 (default), the other configs on request.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|small] [--scaling weak|strong]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|small] [--scaling weak|strong] [--moving-camera]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
 Workloads (config.workload; synthetic, libm-free generators of raytracer_amd/meshgen.py):
@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--moving-camera", action="store_true",
+                    help="N = 1: after the timed region, an orbit of 1 degree per frame (adds `moving_camera` to the line; off by "
+                         "default so that the default command's kernel trace holds the timed region's launches only)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = {"c4": 5, "c5": 5}.get(args.workload, 20)
@@ -400,6 +403,36 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- a camera that moves: every frame differs from the one whose tile durations ordered its queue ------------------
+    # (the timed region above renders ONE camera K times; the history is keyed by the launch shape, not by the camera, so
+    # an orbit of 1 degree per frame about the look-at point shows what the previous frame's durations are worth for the next)
+    moving = None
+    if world == 1 and args.moving_camera:
+        n_mov = min(args.steps, 32)
+        axis = np.asarray(up, np.float64) / np.linalg.norm(up)
+        rel = np.asarray(pos, np.float64) - np.asarray(la, np.float64)
+        cams_mov = []
+        for k in range(1, n_mov + 1):
+            a = np.deg2rad(float(k))
+            rot = rel * np.cos(a) + np.cross(axis, rel) * np.sin(a) + axis * np.dot(axis, rel) * (1.0 - np.cos(a))
+            cams_mov.append(capi.make_camera_frame((np.asarray(la, np.float64) + rot).astype(np.float32), la, up, fov, asp))
+        ctx.synchronize()
+        t1 = time.perf_counter()
+        for cm in cams_mov:
+            ctx.render_part_device(cm, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
+        ctx.synchronize()
+        mov_ms = (time.perf_counter() - t1) * 1e3 / n_mov
+        mov_k = ctx.render_history(n_mov)
+        for _ in range(6):                  # the orbit's last camera, standing still: what that view costs with its own history
+            ctx.render_part_device(cams_mov[-1], W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
+        ctx.synchronize()
+        still_k = ctx.render_history(4)
+        moving = {"ms_per_frame": mov_ms, "kernel_ms": float(np.mean(mov_k)), "kernel_ms_last_frame": float(mov_k[-1]) if len(mov_k) else None,
+                  "kernel_ms_last_view_standing_still": float(np.mean(still_k)), "frames": n_mov,
+                  "Mrays_s": W * H * spp / (mov_ms * 1e-3) / 1e6,
+                  "what": "the camera orbits the look-at point by 1 degree per frame (queued launches); each frame's queue is "
+                          "ordered by the previous, different frame's tile durations"}
+
     # ---- the interface the reference calls (IRayTracer::render -> hvrt_render: host buffers, PCIe included) -----------
     interface_ms = None
     if world == 1 and rank == 0 and args.workload in ("c2", "small"):
@@ -443,6 +476,8 @@ def main():
             out["cold_ms"] = cold_ms                     # first launch of the shape, no tile history
             out["unordered_ms"] = unordered_ms           # HVRT_TILE_ORDER=0: every launch like a first one
             out["unordered_Mrays_s"] = W * H * spp / (unordered_ms * 1e-3) / 1e6 if unordered_ms else None
+            if moving:
+                out["moving_camera"] = moving
         out["roofline_build"] = roof_build
         if interface_ms:
             out["interface_ms"] = interface_ms
