@@ -877,6 +877,13 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     // tile at a time where tiles are long (the head of an ordered queue, the silhouette, supersampled frames),
     // and never more than the waves' even share of what is left of the queue, so that the launch does not end on a
     // wave with a full batch in hand.
+    // Without an order (a first launch) the long tiles lie where the image has them -- side by side along the top and
+    // bottom of a silhouette -- and a wave that sized its batch on cheap background tiles walks into eight of them in a
+    // row: config 2 from 10 degrees to the side took 3.7 ms with no tile above 1.2 ms and a balanced launch of 0.63
+    // (scripts/time_cold_views.py).  Such launches pull one tile at a time (2.4 ms; two at a time 2.8).
+#ifndef HVRT_COLD_BATCH
+#define HVRT_COLD_BATCH 1
+#endif
     constexpr long long PULL_CLOCKS = 400000;
     constexpr uint32_t MAX_BATCH = 8;
     uint32_t batch = 1, slot = 0, slot_end = 0;     // wave-uniform
@@ -986,6 +993,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
             // waves' even share of the slots that are left
             const long long per_tile = (clock64() - batch_clk0) >> __builtin_ctz(batch);     // batch is 1, 2, 4 or 8
             batch = per_tile * 4 > PULL_CLOCKS ? 1u : per_tile * 8 > PULL_CLOCKS ? 2u : per_tile * 16 > PULL_CLOCKS ? 4u : MAX_BATCH;
+            if (!ra.order && batch > (uint32_t)HVRT_COLD_BATCH) batch = (uint32_t)HVRT_COLD_BATCH;
             const uint32_t left = n_queue > slot_end ? n_queue - slot_end : 0u;
             while (batch > 1u && batch * n_waves > left) batch >>= 1;
         }
