@@ -459,7 +459,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     c->ev[7] = c->render_ring[0][1];
     if ((e = hipMalloc((void**)&c->stats, STATS_STATUS * sizeof(uint64_t))) != hipSuccess) return bail("hipMalloc", e);
     c->stats_capacity = STATS_STATUS;
-    if ((e = hipMalloc((void**)&c->tile_counter, 256)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMalloc((void**)&c->tile_counter, 2048)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->cost_sum, 256)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMalloc((void**)&c->cam_dev, sizeof(hvrt_camera_frame) * hvrt_ctx::CAM_SLOTS * hvrt_ctx::CAM_MAX)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipHostMalloc((void**)&c->cam_host, sizeof(hvrt_camera_frame) * hvrt_ctx::CAM_SLOTS * hvrt_ctx::CAM_MAX, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -490,7 +490,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     // that one render() (HVRT_WARMUP=0: not at all).
     const char* warm = getenv("HVRT_WARMUP");
     if (!warm || atoi(warm) != 0) {
-        if ((e = hipMemsetAsync(c->tile_counter, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
+        if ((e = hipMemsetAsync(c->tile_counter, 0, 2048, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         if ((e = hipMemsetAsync(c->cost_sum, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         // the download ring on the copy stream WHILE the main stream is busy with the launches -- that is how a frame
         // comes back (hvrt_render's two-launch path), and streams that are busy at the same time for the first time cost
@@ -1080,6 +1080,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     ra.counters = (unsigned long long*)d_counters;
     ra.hits = (unsigned long long*)d_hits;
     ra.tile_counter = c->tile_counter;
+    ra.n_heads = 8;
     ra.order = reuse ? c->tile_order : nullptr;
     ra.split_tiles = c->split_tiles;
     ra.n_split = c->order_blocks + order_blocks;
@@ -1094,7 +1095,8 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
     const bool queued_behind_ev6 = !c->queue_clean;
     if (!c->queue_clean) {
-        HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // queue head, abandoned count, [8..15] the heads of segment launches
+        HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // [0] a single head, [1] abandoned count, [8..15] the heads of segment launches
+        HIP_TRY(c, hipMemsetAsync(c->tile_counter + 64, 0, 8 * 32 * sizeof(uint32_t), s));   // the queue's eight heads, 128 bytes apart
         HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
     }
     c->queue_clean = false;
@@ -1127,6 +1129,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
                 RenderArgs rs = ra;
                 rs.seg_slots = seg_slots; rs.seg = b;
                 rs.tile_counter = c->tile_counter + 8 + b;
+                rs.n_heads = 1;
                 HIP_TRY(c, launch_render(scene_of(c), rs, c->n_cus, false, s));
                 if (b == 0 && may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
                 HIP_TRY(c, hipEventRecord(c->ev_seg[b], s));
@@ -1165,6 +1168,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     } else {
         c->cost_parity ^= 1;
         HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));
+        HIP_TRY(c, hipMemsetAsync(c->tile_counter + 64, 0, 8 * 32 * sizeof(uint32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity, 0, sizeof(unsigned long long), s));
     }
     c->queue_clean = true;
@@ -1258,6 +1262,7 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
     ra.counters = (unsigned long long*)d_counters;
     ra.hits = nullptr;
     ra.tile_counter = (uint32_t*)(sp + NOALLOC_QUEUE_HEAD);
+    ra.n_heads = 1;
     ra.order = nullptr;                 // no history is kept between these calls: rows of tiles from the middle outwards
     ra.split_tiles = nullptr; ra.n_split = nullptr;
     ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_ticks = 0;   // the plain kernel: no tile is handed on

@@ -64,6 +64,9 @@ struct RenderArgs {
     unsigned long long* counters;  // 2 x u64, nullable
     unsigned long long* hits;      // 1 x u64, nullable: += pixels whose sample-0 ray hit a triangle (the reference's "Ray hits" log line)
     uint32_t* tile_counter;  // persistent-thread work queue head (zeroed before launch)
+    // n_heads == 8: the queue has eight heads, tile_counter[16 + h] (zeroed too); head h hands out the slots
+    // n_waves + 8 k + h, so that the slots of one pull lie eight apart (see render_tiles).  1: the single head above.
+    uint32_t n_heads;
     // Work-queue order.  Slot q of the queue is tile order[q] (null: q itself); a tile is 8x8 pixels of one
     // frame, numbered frame-major.  Every launch leaves the duration of each tile (shader clocks / 16) in
     // tile_cost; the next launch of the same shape starts with the long tiles of this one (k_order_*), because
@@ -165,7 +168,7 @@ hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_
 // (device-visible host memory) <- the number of tiles that qualify for splitting, whatever may_split says.
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
-                              uint32_t* wants_split, uint32_t* clear_heads /* 16 words, nullable */,
+                              uint32_t* wants_split, uint32_t* clear_heads /* 24 words, nullable */,
                               unsigned long long* clear_sum /* nullable */, hipStream_t s);
 // seg_slots[0..n_seg] <- the slot ranges of n_seg launches over the queue launch_order_build left: launch b covers the
 // tiles of tile rows [row_bounds[b], row_bounds[b + 1]) that are in k_render's queue behind the long ones; launch 0

@@ -886,7 +886,21 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #endif
     constexpr long long PULL_CLOCKS = 400000;
     constexpr uint32_t MAX_BATCH = 8;
-    uint32_t batch = 1, slot = 0, slot_end = 0;     // wave-uniform
+    // Eight heads (RenderArgs::n_heads), one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 is the
+    // XCD's number): behind the first n_waves slots the queue is cut into chunks of HVRT_QUEUE_CHUNK slots, chunk c belongs to
+    // head c & 7, and head h hands out the slots of its chunks in order.  The waves of one XCD then work on runs of
+    // neighbouring tiles -- their voxels, lists and records in that XCD's L2 -- instead of every XCD touching every row.
+    // A wave whose head is used up goes on to the next (at most eight rounds: every wave leaves when all are used up).
+#ifndef HVRT_QUEUE_CHUNK_LOG2
+#define HVRT_QUEUE_CHUNK_LOG2 9
+#endif
+    uint32_t batch = 1, slot = 0, rem = 0, g = 0;     // wave-uniform: `rem` slots of this pull are left; g: the next one's number at its head
+    const uint32_t heads = ra.n_heads > 1u ? ra.n_heads : 1u;              // a power of two
+    // (the eight heads lie 128 bytes apart, tile_counter[64 + 32 h]: atomics on one cache line queue up behind one another)
+    uint32_t* const head0 = heads > 1u ? ra.tile_counter + 64 : ra.tile_counter;
+    const uint32_t head_stride = heads > 1u ? 32u : 0u;
+    uint32_t head = blockIdx.x & (heads - 1u);
+    bool own_slot = false;
     long long batch_clk0 = 0;
     const uint32_t n_waves = gridDim.x * RENDER_BLOCK_WAVES;
     // A wave's FIRST slot is its own number: 8192 waves asking the head for one slot each at the same moment is 93 us
@@ -897,25 +911,59 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     for (;;) {
         if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
         given_up = 0xFFFFFFFFu;
-        if (slot == slot_end) {
-            uint32_t got = 0;
+        if (rem == 0u) {
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31       // clocks spent waiting for the queue head | clocks in the loop, per wave
             const long long pull0 = clock64();
 #endif
             if (first_pull) {
-                got = blockIdx.x * RENDER_BLOCK_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
                 first_pull = false;
+                own_slot = true;
+                batch = 1u;
+                slot = slot0 + blockIdx.x * RENDER_BLOCK_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                if (slot >= n_queue) break;
             } else {
-                if (lane_now() == 0) got = atomicAdd(ra.tile_counter, batch);
-                got = n_waves + (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
+                own_slot = false;
+                bool found = false;
+                for (uint32_t tries = 0; tries < heads; ++tries) {
+                    // (a look before the atomic once a head has failed: 8192 waves x 8 used-up heads would otherwise end
+                    // the launch with 65 000 atomics)
+                    uint32_t got = 0;
+                    if (lane_now() == 0) {
+                        uint32_t* const hp = head0 + head * head_stride;
+                        got = tries == 0u ? atomicAdd(hp, batch) : __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    g = (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
+                    const unsigned long long at = heads > 1u
+                        ? (unsigned long long)slot0 + n_waves + ((((unsigned long long)(g >> HVRT_QUEUE_CHUNK_LOG2) * heads + head) << HVRT_QUEUE_CHUNK_LOG2) | (g & ((1u << HVRT_QUEUE_CHUNK_LOG2) - 1u)))
+                        : (unsigned long long)slot0 + n_waves + g;
+                    if (at < (unsigned long long)n_queue) {
+                        if (tries == 0u) { found = true; break; }
+                        // the look says this head has slots left: claim some (it may have run out meanwhile -- then on)
+                        uint32_t got2 = 0;
+                        if (lane_now() == 0) got2 = atomicAdd(head0 + head * head_stride, batch);
+                        g = (uint32_t)__builtin_amdgcn_readlane((int)got2, 0);
+                        const unsigned long long at2 = (unsigned long long)slot0 + n_waves + ((((unsigned long long)(g >> HVRT_QUEUE_CHUNK_LOG2) * heads + head) << HVRT_QUEUE_CHUNK_LOG2) | (g & ((1u << HVRT_QUEUE_CHUNK_LOG2) - 1u)));
+                        if (at2 < (unsigned long long)n_queue) { found = true; break; }
+                    }
+                    head = (head + 1u) & (heads - 1u);
+                }
+                if (!found) break;
             }
-            slot = slot0 + got;
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31
             if (COUNT && lane_now() == 0) { tot_nv += (uint64_t)(clock64() - pull0); tot_nt += 1; }
 #endif
-            if (slot >= n_queue) break;
-            slot_end = slot + batch < n_queue ? slot + batch : n_queue;
+            rem = batch;
             batch_clk0 = clock64();
+        }
+        if (!own_slot) {
+            // slot number g of this head (its chunks, in order); a head's slots rise with g, so the first one past the
+            // queue's end ends the pull
+            const unsigned long long at = heads > 1u
+                ? (unsigned long long)slot0 + n_waves + ((((unsigned long long)(g >> HVRT_QUEUE_CHUNK_LOG2) * heads + head) << HVRT_QUEUE_CHUNK_LOG2) | (g & ((1u << HVRT_QUEUE_CHUNK_LOG2) - 1u)))
+                : (unsigned long long)slot0 + n_waves + g;
+            if (at >= (unsigned long long)n_queue) { rem = 0u; batch = 1u; continue; }
+            slot = (uint32_t)at;
+            ++g;
         }
         uint32_t pulled = 0;
         if (lane_now() == 0) {
@@ -933,7 +981,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
                 pulled = fi * tiles_frame + ty * tiles_x + tx;
             }
         }
-        ++slot;
+        --rem;
         const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)pulled, 0);   // wave-uniform (an SGPR)
         if (tile >= n_tiles) break;      // (never, with a well-formed order: every wave leaves through the queue's end)
         const long long clk0 = clock64();
@@ -988,13 +1036,13 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #endif
             if (ra.hits && !dropped) tot_hits += (uint32_t)__builtin_popcountll(any_lane(inside && px.hit != HVRT_MISS));
         }
-        if (slot == slot_end) {
+        if (rem == 0u) {
             // size of the next pull: PULL_CLOCKS of work at this batch's cost per tile, halved while it exceeds the
             // waves' even share of the slots that are left
             const long long per_tile = (clock64() - batch_clk0) >> __builtin_ctz(batch);     // batch is 1, 2, 4 or 8
             batch = per_tile * 4 > PULL_CLOCKS ? 1u : per_tile * 8 > PULL_CLOCKS ? 2u : per_tile * 16 > PULL_CLOCKS ? 4u : MAX_BATCH;
             if (!ra.order && batch > (uint32_t)HVRT_COLD_BATCH) batch = (uint32_t)HVRT_COLD_BATCH;
-            const uint32_t left = n_queue > slot_end ? n_queue - slot_end : 0u;
+            const uint32_t left = n_queue > slot ? n_queue - slot : 0u;
             while (batch > 1u && batch * n_waves > left) batch >>= 1;
         }
     }
@@ -1184,9 +1232,10 @@ __global__ __launch_bounds__(256) void k_order_place(uint32_t* __restrict__ cost
                                                      const uint32_t* __restrict__ block_count, uint32_t n_blocks,
                                                      uint32_t* __restrict__ order, uint32_t* __restrict__ split_tiles,
                                                      uint32_t* __restrict__ clear_heads, unsigned long long* __restrict__ clear_sum) {
-    // (nullable: the sixteen queue-head words and the cost sum the NEXT launch starts from -- not the sum read here)
+    // (nullable: the 24 queue-head words and the cost sum the NEXT launch starts from -- not the sum read here)
     if (blockIdx.x == 0 && threadIdx.x < 16 && clear_heads) clear_heads[threadIdx.x] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 16 && clear_sum) *clear_sum = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x >= 16 && threadIdx.x < 24 && clear_heads) clear_heads[64 + 32 * (threadIdx.x - 16)] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 24 && clear_sum) *clear_sum = 0ull;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const int cls = i < n ? tile_class(cost[i], *sum, n, slots, may_split) : 0;
     __shared__ uint32_t w[2][4];
