@@ -263,7 +263,9 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* ctx, const hvrt_camera_frame* fram
  * reference renders one frame at a time on one thread, OctreeLikeRayTracer.cpp:71-118).
  *
  * Scheduling note for both forms: each launch records the duration of every 8x8 tile, and the next launch
- * of the same shape (image size, partition, n_frames, spp) on the same scene pulls its tiles longest-first.
+ * of the same shape (image size, partition, n_frames, spp) on the same scene pulls its tiles longest-first,
+ * provided its (first) camera is within 2.5 degrees of that launch's -- a turn of the central ray, or a move of the eye
+ * seen from the grid's centre; HVRT_HISTORY_MAX_DEG changes the limit, 0 removes it.
  * A launch without such history takes the rows of tiles from the middle of the frame outwards.  Only the order
  * of work changes, never a result; HVRT_TILE_ORDER=0 in the environment disables the use of history
  * (HVRT_TILE_SPLIT=0 only the hand-over of over-long tiles to the 16-waves-per-tile kernel). */

@@ -118,6 +118,8 @@ struct hvrt_ctx {
     bool adaptive_split = true;    // HVRT_TILE_SPLIT=0 leaves every tile to k_render
     bool cost_valid = false;
     int cost_key[8] = {};
+    hvrt_camera_frame cost_cam = {};   // the (first) camera of the launch the tile durations come from
+    float history_max_rad = 2.5f * 3.14159265f / 180.0f;   // HVRT_HISTORY_MAX_DEG: durations of a view further away than this are not used (0: always used)
     // the order of the NEXT launch of the same shape is built right behind a launch (queued while its kernel runs, so
     // the three small kernels cost their run time and not three launch latencies in front of the next traversal);
     // likewise the reset of the queue head and of the next launch's cost sum
@@ -471,6 +473,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if (const char* v = getenv("HVRT_OVERLAP")) c->overlap_mode = strcmp(v, "sat") == 0 ? 1 : 0;      // the default of hvrt_set_overlap_test
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_HISTORY_MAX_DEG")) c->history_max_rad = (float)atof(v) * 3.14159265f / 180.0f;
     if (const char* v = getenv("HVRT_TILE_ABORT_US")) {
         const long long us = atoll(v);
         c->abort_ticks = us > 0 ? (us < (1ll << 40) ? us * 100 : (1ll << 47)) : 0;      // 0: the plain kernel is launched
@@ -1019,6 +1022,25 @@ int hvrt_part_rows(int height, int tile_rows, int part, int n_parts) {
 // by render_batch_part when it took that route (used); otherwise the frame is one launch as always.
 struct SegPlan { int n = 0; uint32_t row[9] = {}; bool used = false; };
 
+// How far apart two views are, as an angle: the larger of the angle between their central rays and the angle under
+// which the move of the eye is seen from the grid's centre.  (NaNs compare false: such a view counts as near.)
+static float view_distance(const hvrt_ctx* c, const hvrt_camera_frame& a, const hvrt_camera_frame& b) {
+    const GridParams g = scene_of(c).g;
+    double da[3], db[3], la = 0, lb = 0, dot = 0, move = 0, dist = 0;
+    const double centre[3] = { 0.5 * ((double)g.mnx + g.bxx), 0.5 * ((double)g.mny + g.bxy), 0.5 * ((double)g.mnz + g.bxz) };
+    for (int k = 0; k < 3; ++k) {
+        da[k] = (double)a.lower_left[k] + 0.5 * a.horizontal[k] + 0.5 * a.vertical[k] - a.origin[k];
+        db[k] = (double)b.lower_left[k] + 0.5 * b.horizontal[k] + 0.5 * b.vertical[k] - b.origin[k];
+        la += da[k] * da[k]; lb += db[k] * db[k]; dot += da[k] * db[k];
+        move += ((double)a.origin[k] - b.origin[k]) * ((double)a.origin[k] - b.origin[k]);
+        dist += ((double)a.origin[k] - centre[k]) * ((double)a.origin[k] - centre[k]);
+    }
+    double turn = 0.0;
+    if (la > 0 && lb > 0) { double cs = dot / sqrt(la * lb); cs = cs > 1.0 ? 1.0 : cs < -1.0 ? -1.0 : cs; turn = acos(cs); }
+    const double seen = dist > 0 ? atan(sqrt(move / dist)) : (move > 0 ? 1.5707963 : 0.0);
+    return (float)(turn > seen ? turn : seen);
+}
+
 // hvrt_render_batch_part_device plus d_hits (nullable): one u64 that receives the number of pixels whose sample-0 ray
 // hit a triangle (the host-facing entry points keep it for hvrt_last_hit_count)
 static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_frames, int width, int height,
@@ -1066,7 +1088,11 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     if (int r = ensure<uint32_t>(c, c->split_tiles, c->split_tiles_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->abandoned, c->abandoned_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, 2 * (order_blocks + 1))) return r;
-    const bool reuse = c->adaptive_order && c->cost_valid && c->order_ahead && !grew && memcmp(key, c->cost_key, sizeof key) == 0;
+    // ... and of a view near this one: a queue ordered by the durations of a view a few degrees away is worse than an
+    // unordered one (config 2, an orbit in steps of 2 / 3 / 5 / 7 degrees: 1.55 / 1.71 / 1.89 / 2.09 ms per frame with the
+    // previous frame's durations, 1.69-1.75 with none; scripts/time_moving.py), so past 2.5 degrees this is a first launch
+    const bool view_moved = c->history_max_rad > 0.0f && c->cost_valid && view_distance(c, frames[0], c->cost_cam) > c->history_max_rad;
+    const bool reuse = c->adaptive_order && c->cost_valid && c->order_ahead && !grew && !view_moved && memcmp(key, c->cost_key, sizeof key) == 0;
     c->order_ahead = false;
 
     RenderArgs ra;
@@ -1173,6 +1199,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     }
     c->queue_clean = true;
     memcpy(c->cost_key, key, sizeof key);
+    c->cost_cam = frames[0];
     c->cost_valid = true;
     c->render_pending = true;
     return HVRT_OK;
