@@ -283,6 +283,46 @@ def test_launches_queued_without_waiting_keep_their_durations_and_their_bytes(ct
         assert np.array_equal(h.cpu().numpy().view(np.uint32), want_hit), f"queued launch {k} with split tiles: hit ids differ"
 
 
+def _orbit_camera(mn, mx, degrees, aspect):
+    pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=aspect)
+    a = np.deg2rad(degrees)
+    rel = np.asarray(pos, np.float64) - np.asarray(la, np.float64)
+    axis = np.asarray(up, np.float64)
+    rot = rel * np.cos(a) + np.cross(axis, rel) * np.sin(a) + axis * np.dot(axis, rel) * (1.0 - np.cos(a))
+    return capi.make_camera_frame((np.asarray(la, np.float64) + rot).astype(np.float32), la, up, fov, asp)
+
+
+@pytest.mark.parametrize("max_deg", [None, "0"])
+def test_a_camera_that_moves_changes_only_the_order(monkeypatch, max_deg):
+    """Launches of one shape whose camera moves: steps of 1 degree are ordered by the previous frame's tile durations, a jump of
+    20 degrees is past HVRT_HISTORY_MAX_DEG (2.5) and runs like a first launch -- or, with the limit removed, is ordered by
+    the far view's durations.  Queued without waiting; every frame must be the oracle's, bit for bit (rgb and hit ids)."""
+    import torch
+    import raytracer_amd as ra
+    if max_deg is not None:
+        monkeypatch.setenv("HVRT_HISTORY_MAX_DEG", max_deg)
+    c = ra.Context(0)
+    try:
+        tris = meshgen.skewed_statue(24, 120)
+        sc, mn, mx = setup_scene(c, tris, (32, 32, 32))
+        W, H = 640, 360
+        angles = [0.0, 0.0, 1.0, 2.0, 22.0, 23.0, 23.0, 3.0, -40.0]
+        cams = [_orbit_camera(mn, mx, a, W / H) for a in angles]
+        dev = torch.device("cuda:0")
+        outs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in angles]
+        hits = [torch.zeros((H, W), dtype=torch.int32, device=dev) for _ in angles]
+        torch.cuda.synchronize()
+        for cam, o, h in zip(cams, outs, hits):
+            c.render_part_device(cam, W, H, 1, 0, H, 0, 1, d_rgb=o.data_ptr(), d_hit=h.data_ptr())     # no wait in between
+        c.synchronize()
+        for a, cam, o, h in zip(angles, cams, outs, hits):
+            exp = sc.render(cam, W, H, threads=16)
+            assert np.array_equal(o.cpu().numpy().view(np.uint32), np.ascontiguousarray(exp[0], np.float32).reshape(H, W, 3).view(np.uint32)), a
+            assert np.array_equal(h.cpu().numpy().view(np.uint32), np.asarray(exp[1]).reshape(H, W).view(np.uint32)), a
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_split_tiles_change_nothing(ctx, mode):
     """From the second launch of a shape on, tiles that took longer than a balanced launch would are rendered by
