@@ -491,10 +491,12 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     // The reference constructs a tracer per image and renders once (TraceImages.cpp:215-229): what a process pays once
     // per hardware queue -- its scratch memory, the first pass through the download ring -- is paid here, not inside
     // that one render() (HVRT_WARMUP=0: not at all).
+    // (the queue scratch starts at zero whatever HVRT_WARMUP says: the word the split kernel's workgroups report to is never
+    // reset afterwards, it is compared with a running total)
+    if ((e = hipMemsetAsync(c->tile_counter, 0, 2048, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
+    if ((e = hipMemsetAsync(c->cost_sum, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
     const char* warm = getenv("HVRT_WARMUP");
     if (!warm || atoi(warm) != 0) {
-        if ((e = hipMemsetAsync(c->tile_counter, 0, 2048, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
-        if ((e = hipMemsetAsync(c->cost_sum, 0, 256, c->stream)) != hipSuccess) return bail("hipMemsetAsync", e);
         // the download ring on the copy stream WHILE the main stream is busy with the launches -- that is how a frame
         // comes back (hvrt_render's two-launch path), and streams that are busy at the same time for the first time cost
         // the process a hardware queue's set-up -- then once on the main stream
