@@ -113,6 +113,12 @@ int hvrt_synchronize(hvrt_ctx* ctx);
  *                CPU restatement and against brute force over all triangles.  Shading, outputs and counters keep
  *                their meaning (a ray that misses the grid visits no voxel). */
 int hvrt_set_mode(hvrt_ctx* ctx, int mode);
+int hvrt_get_mode(const hvrt_ctx* ctx);
+/* Forgets the context's mesh and grid and returns every per-scene setting (mode, overlap test, deferred data) to its
+ * default, keeping the device buffers, streams and warmed-up queues: what a pool of contexts calls between two tracers.
+ * The reference constructs a tracer per image (TraceImages.cpp:215-229); creating a context per image would pay the
+ * runtime's start-up each time. */
+int hvrt_clear_scene(hvrt_ctx* ctx);
 /* Which voxels of a triangle's bounding-box range list it, for all later hvrt_build_grid calls.
  *   0 (default)  all of them: the reference's voxelizer (SceneCreator.cpp:197-281), the only rule under which the CSR is
  *                the reference's grid bit for bit.
@@ -127,6 +133,12 @@ int hvrt_set_mode(hvrt_ctx* ctx, int mode);
  *                nowhere under this rule. */
 int hvrt_set_overlap_test(hvrt_ctx* ctx, int mode);
 int hvrt_get_timings(const hvrt_ctx* ctx, hvrt_timings* out);
+/* Width in bits (16 or 32) of the per-voxel counters the NEXT hvrt_build_grid counts into first.  A context starts
+ * with 16 (two counters per word: half the bytes to clear and scan); a build in which some voxel's list outgrows 16 bits
+ * notices (its two reference totals differ), repeats its front with 32-bit counters and leaves the context at 32 for
+ * good.  HVRT_BUILD_NARROW=0 and the separating-axis rule start at 32.  The CSR is the same either way.  No reference
+ * counterpart (its lists are std::vectors, SceneCreator.cpp:205). */
+int hvrt_get_counter_width(const hvrt_ctx* ctx);
 /* Durations of the last asynchronous traversals (hvrt_render_part_device, hvrt_render_batch_part_device, the noalloc
  * form), for callers that queue several launches and wait once: waits for the stream, then writes up to max_entries
  * durations in milliseconds (HIP events around each traversal, like hvrt_timings.render_ms), the oldest of them first --
@@ -312,29 +324,53 @@ int hvrt_trace_device(hvrt_ctx* ctx, const void* d_origins, const void* d_dirs, 
 /* Device -> the caller's (pageable) host memory through the context's ring of pinned chunks (what hvrt_render uses for
  * its frames: a plain DMA into pageable memory runs at a third of the link).  Synchronous.  No reference counterpart. */
 int hvrt_download(hvrt_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
+/* The same with a scattered destination: the source is one compact run of blocks of block_bytes (the last may be
+ * shorter), block j lands at dst + j * dst_stride (dst_stride >= block_bytes).  How a member of a device group puts
+ * its row tiles where they belong in the caller's frame.  Synchronous.  No reference counterpart. */
+int hvrt_download_blocks(hvrt_ctx* ctx, void* dst, const void* d_src, uint64_t bytes, uint64_t block_bytes, uint64_t dst_stride);
 
 /* ---- several GPUs of one node ---------------------------------------------------------------
  * No counterpart in the reference (one thread on one CPU); the seam a maintainer would use is the tracer factory,
- * TraceImages.cpp:464-484.  One process, one context per device: the scene is replicated, a frame's 16-row tiles
- * are interleaved over the members (tile k -> member k % n), the slabs travel to member 0 -- RCCL (ncclCommInitAll,
- * ncclBroadcast of the scene, grouped ncclSend / ncclRecv of the slabs; librccl is opened at run time) or, with
- * HVRT_GROUP_TRANSPORT=copy or when a device is listed twice, device-to-device copies -- and member 0 reassembles
- * the frame.  Results are bit for bit those of one context.  A group of one device needs no transport at all. */
+ * TraceImages.cpp:464-484.  One process, one context per device, one host thread per member: the scene is replicated, a
+ * frame's 16-row tiles are interleaved over the members (tile k -> member k % n).  A frame wanted in HOST memory
+ * (hvrt_group_render -- what IRayTracer::render returns, IRayTracer.h:28) is copied out by the members themselves, each
+ * its own tiles over its own PCIe link straight into the caller's arrays; nothing crosses xGMI.  A frame wanted in
+ * DEVICE memory (hvrt_group_render_device) is gathered on member 0 -- RCCL (ncclCommInitAll, grouped ncclSend / ncclRecv
+ * of the slabs; librccl is opened at run time) or, with HVRT_GROUP_TRANSPORT=copy or when a device is listed twice,
+ * device-to-device copies -- and reassembled there.  The scene travels the same way (ncclBroadcast, or copies).
+ * Results are bit for bit those of one context.  A group of one device needs no transport at all. */
 typedef struct hvrt_group hvrt_group;
+typedef struct hvrt_group_timings {
+    float create_ms;      /* hvrt_group_create: every member's hvrt_create (concurrent) + the transport's set-up; host clock */
+    float replicate_ms;   /* last hvrt_group_replicate_scene; host clock */
+    float render_ms;      /* last render: the longest member's traversal (HIP events, as hvrt_timings.render_ms) */
+    float download_ms;    /* last hvrt_group_render: the longest member's copy into the caller's arrays; host clock */
+    float total_ms;       /* last render, call to return; host clock */
+} hvrt_group_timings;
 int hvrt_device_count(void);                                  /* visible HIP devices (0 when there is none) */
 int hvrt_group_create(hvrt_group** out, const int* device_ids, int n_devices);
 void hvrt_group_destroy(hvrt_group* group);
 const char* hvrt_group_last_error(const hvrt_group* group);   /* group == NULL: why hvrt_group_create failed (this thread) */
 int hvrt_group_size(const hvrt_group* group);
 const char* hvrt_group_transport(const hvrt_group* group);    /* "rccl", "copy" or "none" (one member) */
+int hvrt_group_get_timings(const hvrt_group* group, hvrt_group_timings* out);
 /* Member i's context (owned by the group).  Member 0 is where the caller sets the mesh and builds or ingests the grid. */
 hvrt_ctx* hvrt_group_member(hvrt_group* group, int i);
-/* Member 0's mesh and CSR to every other member (each derives its own acceleration data).  Synchronous. */
+/* Member 0's mesh and CSR to every other member (each derives its own acceleration data, all at once).  Synchronous. */
 int hvrt_group_replicate_scene(hvrt_group* group);
-/* hvrt_render over the group: rgb W*H*3 floats (host), counters / hits nullable (summed over the members;
- * hits = pixels whose sample-0 ray hit a triangle, as hvrt_last_hit_count).  Synchronous. */
+/* hvrt_set_mode on every member.  (The renders below also hand member 0's mode to the others, so a caller that only
+ * ever talks to member 0's context -- hvrt_set_mode(hvrt_group_member(g, 0), 1) -- gets one mode over the whole frame.) */
+int hvrt_group_set_mode(hvrt_group* group, int mode);
+/* hvrt_render over the group: rgb W*H*3 floats, hit_id / t W*H (nullable), host memory; counters / hits nullable
+ * (summed over the members; hits = pixels whose sample-0 ray hit a triangle, as hvrt_last_hit_count).  Synchronous. */
 int hvrt_group_render(hvrt_group* group, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,
-                      float* rgb, uint64_t counters[2], uint64_t* hits);
+                      float* rgb, uint32_t* hit_id, float* t, uint64_t counters[2], uint64_t* hits);
+/* The same frame left in member 0's device memory: *d_rgb <- W*H*3 floats owned by the group, valid until its next
+ * render.  Synchronous.  hvrt_group_last_exchange_bytes: what the last render moved between devices (0 after
+ * hvrt_group_render). */
+int hvrt_group_render_device(hvrt_group* group, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,
+                             void** d_rgb, uint64_t counters[2], uint64_t* hits);
+double hvrt_group_last_exchange_bytes(const hvrt_group* group);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,8 @@ SYMBOLS = [
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc", "hvrt_last_hit_count",
     "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count", "hvrt_render_history", "hvrt_set_overlap_test",
     "hvrt_group_create", "hvrt_group_destroy", "hvrt_group_last_error", "hvrt_group_size", "hvrt_group_transport",
-    "hvrt_group_member", "hvrt_group_replicate_scene", "hvrt_group_render",
+    "hvrt_group_member", "hvrt_group_replicate_scene", "hvrt_group_render", "hvrt_group_render_device", "hvrt_group_set_mode",
+    "hvrt_group_get_timings", "hvrt_group_last_exchange_bytes", "hvrt_get_mode", "hvrt_clear_scene", "hvrt_download_blocks", "hvrt_get_counter_width",
 ]
 
 
@@ -54,6 +55,11 @@ class Timings(C.Structure):
                 ("build_fill_ms", C.c_float), ("build_sort_ms", C.c_float), ("build_expand_ms", C.c_float),
                 ("render_ms", C.c_float),
                 ("trace_ms", C.c_float)]
+
+
+class GroupTimings(C.Structure):
+    _fields_ = [("create_ms", C.c_float), ("replicate_ms", C.c_float), ("render_ms", C.c_float),
+                ("download_ms", C.c_float), ("total_ms", C.c_float)]
 
 
 HIT_DTYPE = np.dtype([("hit", "<u4"), ("t", "<f4"), ("point", "<f4", 3), ("origin", "<f4", 3),
@@ -124,7 +130,16 @@ def load_library() -> C.CDLL:
     lib.hvrt_group_member.argtypes = [vp, C.c_int]
     lib.hvrt_group_member.restype = vp
     lib.hvrt_group_replicate_scene.argtypes = [vp]
-    lib.hvrt_group_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp]
+    lib.hvrt_group_render.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.hvrt_group_render_device.argtypes = [vp, C.POINTER(CameraFrame), C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(vp), vp, vp]
+    lib.hvrt_group_set_mode.argtypes = [vp, C.c_int]
+    lib.hvrt_group_get_timings.argtypes = [vp, C.POINTER(GroupTimings)]
+    lib.hvrt_group_last_exchange_bytes.argtypes = [vp]
+    lib.hvrt_group_last_exchange_bytes.restype = C.c_double
+    lib.hvrt_get_mode.argtypes = [vp]
+    lib.hvrt_get_counter_width.argtypes = [vp]
+    lib.hvrt_clear_scene.argtypes = [vp]
+    lib.hvrt_download_blocks.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, C.c_uint64]
     lib.hvrt_set_deferred_accel.argtypes = [vp, C.c_int]
     lib.hvrt_set_overlap_test.argtypes = [vp, C.c_int]
     lib.hvrt_finish_accel.argtypes = [vp]
@@ -189,7 +204,6 @@ def default_camera(min_bound, max_bound, view: str = "front", aspect: float = 80
     return pos, center, up, 60.0, float(np.float32(aspect))
 
 
-@dataclass
 class Group:
     """Several GPUs of one node (include/hvrt.h, group section): member 0 holds the scene the caller sets, replicate()
     hands it to the others, render() traces a frame over all of them."""
@@ -202,12 +216,16 @@ class Group:
         if rc != 0:
             raise HvrtError(rc, self._lib.hvrt_group_last_error(None).decode())
         self._g = h
-        self.root = Context.__new__(Context)           # member 0, owned by the group
-        self.root._lib, self.root._h, self.root._borrowed = self._lib, C.c_void_p(self._lib.hvrt_group_member(h, 0)), True
+        self.root = self.member(0)                     # member 0, owned by the group
 
     def _ck(self, rc):
         if rc != 0:
             raise HvrtError(rc, self._lib.hvrt_group_last_error(self._g).decode())
+
+    def member(self, i: int) -> "Context":
+        c = Context.__new__(Context)
+        c._lib, c._h, c._borrowed = self._lib, C.c_void_p(self._lib.hvrt_group_member(self._g, i)), True
+        return c
 
     @property
     def size(self) -> int:
@@ -220,13 +238,39 @@ class Group:
     def replicate(self):
         self._ck(self._lib.hvrt_group_replicate_scene(self._g))
 
-    def render(self, frame: CameraFrame, width: int, height: int, spp: int = 1, seed: int = 0):
+    def set_mode(self, mode: int):
+        self._ck(self._lib.hvrt_group_set_mode(self._g, mode))
+
+    def timings(self) -> GroupTimings:
+        t = GroupTimings()
+        self._ck(self._lib.hvrt_group_get_timings(self._g, C.byref(t)))
+        return t
+
+    @property
+    def last_exchange_bytes(self) -> float:
+        return float(self._lib.hvrt_group_last_exchange_bytes(self._g))
+
+    def render(self, frame: CameraFrame, width: int, height: int, spp: int = 1, seed: int = 0, want_hit=False, want_t=False):
+        """Host frame: every member copies its own row tiles into the arrays returned here."""
         rgb = np.empty((height, width, 3), np.float32)
+        hit = np.empty((height, width), np.uint32) if want_hit else None
+        t = np.empty((height, width), np.float32) if want_t else None
         cnt = np.zeros(2, np.uint64)
         hits = C.c_uint64()
-        self._ck(self._lib.hvrt_group_render(self._g, C.byref(frame), width, height, spp, seed, _ptr(rgb), _ptr(cnt),
-                                             C.cast(C.byref(hits), C.c_void_p)))
+        self._ck(self._lib.hvrt_group_render(self._g, C.byref(frame), width, height, spp, seed, _ptr(rgb), _ptr(hit), _ptr(t),
+                                             _ptr(cnt), C.cast(C.byref(hits), C.c_void_p)))
+        if want_hit or want_t:
+            return rgb, hit, t, cnt, int(hits.value)
         return rgb, cnt, int(hits.value)
+
+    def render_device(self, frame: CameraFrame, width: int, height: int, spp: int = 1, seed: int = 0):
+        """Frame gathered and reassembled in member 0's memory; returns (device address, counters, hits)."""
+        d = C.c_void_p()
+        cnt = np.zeros(2, np.uint64)
+        hits = C.c_uint64()
+        self._ck(self._lib.hvrt_group_render_device(self._g, C.byref(frame), width, height, spp, seed, C.byref(d), _ptr(cnt),
+                                                    C.cast(C.byref(hits), C.c_void_p)))
+        return d.value, cnt, int(hits.value)
 
     def close(self):
         if getattr(self, "_g", None):
@@ -241,6 +285,7 @@ class Group:
             pass
 
 
+@dataclass
 class BuildResult:
     info: GridInfo
     timings: Timings
@@ -369,6 +414,27 @@ class Context:
     def set_mode(self, mode: int):
         """0 = the reference's traversal (default), 1 = nearest-hit mode."""
         self._ck(self._lib.hvrt_set_mode(self._h, mode))
+
+    def get_mode(self) -> int:
+        return self._lib.hvrt_get_mode(self._h)
+
+    def counter_width(self) -> int:
+        """16 or 32: the per-voxel counters the next build_grid counts into first (hvrt_get_counter_width)."""
+        return self._lib.hvrt_get_counter_width(self._h)
+
+    def clear_scene(self):
+        """Forget mesh and grid, settings back to their defaults; buffers and warmed-up queues are kept."""
+        self._ck(self._lib.hvrt_clear_scene(self._h))
+
+    def download(self, d_src: int, out: np.ndarray):
+        self._ck(self._lib.hvrt_download(self._h, _ptr(out), C.c_void_p(d_src), out.nbytes))
+        return out
+
+    def download_blocks(self, d_src: int, n_bytes: int, out: np.ndarray, block_bytes: int, dst_stride: int, dst_offset: int = 0):
+        """Compact device run -> blocks `dst_stride` bytes apart in `out` (hvrt_download_blocks)."""
+        self._ck(self._lib.hvrt_download_blocks(self._h, C.c_void_p(out.ctypes.data + dst_offset), C.c_void_p(d_src), n_bytes,
+                                                block_bytes, dst_stride))
+        return out
 
     def set_deferred_accel(self, on: bool):
         """Keep libhvrt's derived acceleration data out of build_grid / set_grid_csr (built at first use instead)."""

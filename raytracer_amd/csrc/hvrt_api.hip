@@ -216,12 +216,31 @@ int bind(hvrt_ctx* c) {
 // Device -> caller's (pageable) host memory on stream s.  Small copies are issued directly and complete at the
 // caller's next stream synchronisation; large ones are pipelined through the context's ring of pinned chunks -- this
 // thread queues the DMAs, PIN_THREADS helper threads copy finished chunks out -- and have completed on return.
-int download(hvrt_ctx* c, void* dst, const void* src, uint64_t bytes, hipStream_t s) {
+// The source is one compact run of bytes; the destination may be cut into blocks: block j (block_bytes of the source,
+// the last one possibly shorter) lands at dst + j * dst_stride.  That is how a member of a device group puts its row
+// tiles where they belong in the caller's frame (hvrt_group_render); block_bytes >= bytes is the plain copy.
+int download(hvrt_ctx* c, void* dst, const void* src, uint64_t bytes, hipStream_t s, uint64_t block_bytes = ~0ull, uint64_t dst_stride = 0) {
     if (bytes == 0) return HVRT_OK;
     constexpr uint64_t CH = hvrt_ctx::PIN_CHUNK;
     constexpr int R = hvrt_ctx::PIN_RING, T = hvrt_ctx::PIN_THREADS;
-    if (bytes < 4 * CH || !c->pin_ring) {
-        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    const bool blocks = block_bytes < bytes;
+    if (!blocks) { block_bytes = bytes; dst_stride = 0; }
+    // where the source bytes [off, off + len) go: piece by piece, a piece never crossing a block boundary
+    auto scatter = [&](uint64_t off, uint64_t len, auto&& piece) {
+        while (len) {
+            const uint64_t j = off / block_bytes, within = off - j * block_bytes;
+            const uint64_t n = block_bytes - within < len ? block_bytes - within : len;
+            piece((char*)dst + j * dst_stride + within, off, n);
+            off += n; len -= n;
+        }
+    };
+    // (a scattered copy takes the ring from one chunk on: its blocks would otherwise be as many small DMAs into pageable memory)
+    if (bytes < (blocks ? CH : 4 * CH) || !c->pin_ring) {
+        hipError_t err = hipSuccess;
+        scatter(0, bytes, [&](char* d, uint64_t off, uint64_t n) {
+            if (err == hipSuccess) err = hipMemcpyAsync(d, (const char*)src + off, n, hipMemcpyDeviceToHost, s);
+        });
+        if (err != hipSuccess) return fail(c, HVRT_ERR_HIP, "download: %s", hipGetErrorString(err));
         return HVRT_OK;
     }
     const uint64_t n = (bytes + CH - 1) / CH;
@@ -235,7 +254,8 @@ int download(hvrt_ctx* c, void* dst, const void* src, uint64_t bytes, hipStream_
         for (uint64_t k = (uint64_t)t; k < n; k += T) {
             while (!issued[k].load(std::memory_order_acquire)) { if (failed.load()) return; std::this_thread::yield(); }
             if (hipEventSynchronize(c->pin_ev[k % R]) != hipSuccess) { failed.store(1); return; }
-            memcpy((char*)dst + k * CH, c->pin_ring + (k % R) * CH, size_of(k));
+            const char* from = c->pin_ring + (k % R) * CH;
+            scatter(k * CH, size_of(k), [&](char* d, uint64_t off, uint64_t len) { memcpy(d, from + (off - k * CH), len); });
             emptied[k].store(1, std::memory_order_release);
         }
     };
@@ -598,6 +618,36 @@ int hvrt_set_mode(hvrt_ctx* c, int mode) {
     if (mode != 0 && mode != 1) return fail(c, HVRT_ERR_INVALID, "set_mode: mode %d is neither 0 (reference) nor 1 (nearest hit)", mode);
     if (mode != c->mode) c->cost_valid = false;     // tile durations of the other mode say nothing about this one
     c->mode = mode;
+    return HVRT_OK;
+}
+
+int hvrt_get_mode(const hvrt_ctx* c) { return c ? c->mode : HVRT_ERR_INVALID; }
+
+int hvrt_get_counter_width(const hvrt_ctx* c) { return c ? (c->narrow_counters && c->overlap_mode == 0 ? 16 : 32) : HVRT_ERR_INVALID; }
+
+int hvrt_clear_scene(hvrt_ctx* c) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    (void)join_distance_field(c, c->stream);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->n_tris = 0;
+    c->has_grid = false;
+    c->accel_pending = false;
+    c->occ_bits_valid = false;
+    c->ref_rec_valid = false;
+    c->vox_of = nullptr;
+    c->n_refs = c->n_occupied = 0;
+    c->max_list = 0;
+    c->cost_valid = false;
+    c->order_ahead = false;
+    c->mode = 0;
+    c->defer_accel = false;
+    const char* v = getenv("HVRT_OVERLAP");
+    c->overlap_mode = (v && strcmp(v, "sat") == 0) ? 1 : 0;
+    c->last_hits = 0;
+    c->tm = hvrt_timings{};
+    c->error.clear();
     return HVRT_OK;
 }
 
@@ -1054,7 +1104,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     if (!frames) return fail(c, HVRT_ERR_INVALID, "render: null camera frame");
     if (n_frames < 1 || n_frames > HVRT_MAX_BATCH_FRAMES)
         return fail(c, HVRT_ERR_INVALID, "render: n_frames %d outside 1..%d", n_frames, HVRT_MAX_BATCH_FRAMES);
-    if (width < 1 || height < 1 || (uint64_t)width * height > 0x7FFFFFFFull)
+    if (width < 1 || height < 1 || width > 0x7FFFFFF0 || height > 0x7FFFFFF0 || (uint64_t)width * height > 0x7FFFFFFFull)
         return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
     if (spp < 1) return fail(c, HVRT_ERR_INVALID, "render: spp must be >= 1");
     if (tile_rows < 1 || n_parts < 1 || part < 0 || part >= n_parts)
@@ -1242,6 +1292,16 @@ int hvrt_download(hvrt_ctx* c, void* dst, const void* d_src, uint64_t bytes) {
     return hvrt_synchronize(c);
 }
 
+int hvrt_download_blocks(hvrt_ctx* c, void* dst, const void* d_src, uint64_t bytes, uint64_t block_bytes, uint64_t dst_stride) {
+    if (!c) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (bytes && (!dst || !d_src)) return fail(c, HVRT_ERR_INVALID, "download_blocks: null pointer");
+    if (block_bytes == 0 || (block_bytes < bytes && dst_stride < block_bytes))
+        return fail(c, HVRT_ERR_INVALID, "download_blocks: blocks of %llu bytes %llu bytes apart overlap", (unsigned long long)block_bytes, (unsigned long long)dst_stride);
+    if (int r = download(c, dst, d_src, bytes, c->stream, block_bytes, dst_stride)) return r;
+    return hvrt_synchronize(c);
+}
+
 int hvrt_render_history(hvrt_ctx* c, float* ms, int max_entries) {
     if (!c) return -1;
     if (bind(c)) return -1;
@@ -1264,7 +1324,7 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
     if (int r = bind(c)) return r;
     if (int r = require_scene(c, false)) return r;
     if (!frame) return fail(c, HVRT_ERR_INVALID, "render: null camera frame");
-    if (width < 1 || height < 1 || (uint64_t)width * height > 0x7FFFFFFFull)
+    if (width < 1 || height < 1 || width > 0x7FFFFFF0 || height > 0x7FFFFFF0 || (uint64_t)width * height > 0x7FFFFFFFull)
         return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
     if (spp < 1) return fail(c, HVRT_ERR_INVALID, "render: spp must be >= 1");
     if (tile_rows < 1 || n_parts < 1 || part < 0 || part >= n_parts)
@@ -1314,7 +1374,7 @@ int hvrt_render(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int heig
                 float* rgb, uint32_t* hit_id, float* t, uint64_t counters[2]) {
     if (!c) return HVRT_ERR_INVALID;
     if (int r = bind(c)) return r;
-    if (width < 1 || height < 1) return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
+    if (width < 1 || height < 1 || width > 0x7FFFFFF0 || height > 0x7FFFFFF0) return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
     const uint64_t npx = (uint64_t)width * height;
     if (rgb) if (int r = ensure_bytes(c, c->out_buf[0], c->out_cap[0], npx * 12)) return r;
     if (hit_id) if (int r = ensure_bytes(c, c->out_buf[1], c->out_cap[1], npx * 4)) return r;
@@ -1379,7 +1439,7 @@ int hvrt_render_views_rgb8(hvrt_ctx* c, const hvrt_camera_frame* frames, int n_f
                            uint8_t* rgb8, uint32_t* hit_id, uint64_t counters[2]) {
     if (!c) return HVRT_ERR_INVALID;
     if (int r = bind(c)) return r;
-    if (width < 1 || height < 1) return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
+    if (width < 1 || height < 1 || width > 0x7FFFFFF0 || height > 0x7FFFFFF0) return fail(c, HVRT_ERR_INVALID, "render: bad image size %d x %d", width, height);
     if (n_frames < 1 || n_frames > HVRT_MAX_BATCH_FRAMES)
         return fail(c, HVRT_ERR_INVALID, "render: n_frames %d outside 1..%d", n_frames, HVRT_MAX_BATCH_FRAMES);
     if (!rgb8) return fail(c, HVRT_ERR_INVALID, "render: null output");
@@ -1470,9 +1530,9 @@ int hvrt_trace_device(hvrt_ctx* c, const void* d_origins, const void* d_dirs, ui
 // for hvrt_group.hip: hvrt_render_part_device that also counts the pixels whose (sample-0) ray hit a triangle
 namespace hvrt {
 int render_part_counting_hits(hvrt_ctx* c, const hvrt_camera_frame* frame, int width, int height, int spp, uint32_t seed,
-                              int tile_rows, int part, int n_parts, void* d_rgb, void* d_counters, void* d_hits) {
+                              int tile_rows, int part, int n_parts, void* d_rgb, void* d_hit_id, void* d_t, void* d_counters, void* d_hits) {
     const int rows = hvrt_part_rows(height, tile_rows, part, n_parts);
-    return render_batch_part(c, frame, 1, width, height, spp, seed, tile_rows, part, n_parts, rows, d_rgb, nullptr, nullptr,
+    return render_batch_part(c, frame, 1, width, height, spp, seed, tile_rows, part, n_parts, rows, d_rgb, d_hit_id, d_t,
                              d_counters, d_hits);
 }
 }  // namespace hvrt

@@ -1,8 +1,11 @@
 // HipVoxelRayTracer.cpp -- see the header.  Plain C++17, links libhvrt; no HIP headers.
 #include "HipVoxelRayTracer.hpp"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <stdexcept>
 
 #include "Logger.hpp"
@@ -32,9 +35,74 @@ inline void ck(hvrt_ctx* c, int rc, const char* what) {
 
 // ------------------------------------------------------------------------------------------ HipScene
 
+namespace {
+
+// Contexts and device groups outlive the scenes that use them.  The reference constructs a tracer per image
+// (TraceImages.cpp:215-229) and HipVoxelRayTracer(const VoxelGrid&) makes a scene per tracer: a context per scene would pay
+// hvrt_create -- 100-200 ms of runtime start-up and queue warm-up per device, plus the communicator of a group -- for
+// every image.  A scene takes an idle context (or group) of the same device list from here, cleared of its last scene
+// (hvrt_clear_scene: the device buffers stay, grow-only), and hands it back when it dies.  HVRT_CONTEXT_CACHE=0: no
+// pool, every scene creates and destroys its own.
+class ContextPool {
+public:
+    static ContextPool& get() {
+        (void)hvrt_device_count();      // the HIP runtime starts BEFORE this object exists, so it is torn down after it
+        static ContextPool p;
+        return p;
+    }
+    hvrt_ctx* takeContext(int device) {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = ctxs_.find(device);
+        if (it == ctxs_.end()) return nullptr;
+        hvrt_ctx* c = it->second;
+        ctxs_.erase(it);
+        return c;
+    }
+    hvrt_group* takeGroup(const std::string& key) {
+        std::lock_guard<std::mutex> lk(mu_);
+        auto it = groups_.find(key);
+        if (it == groups_.end()) return nullptr;
+        hvrt_group* g = it->second;
+        groups_.erase(it);
+        return g;
+    }
+    void give(int device, hvrt_ctx* c) {
+        if (!enabled_) { hvrt_destroy(c); return; }
+        std::lock_guard<std::mutex> lk(mu_);
+        ctxs_.emplace(device, c);
+    }
+    void give(const std::string& key, hvrt_group* g) {
+        if (!enabled_) { hvrt_group_destroy(g); return; }
+        std::lock_guard<std::mutex> lk(mu_);
+        groups_.emplace(key, g);
+    }
+    void clear() {
+        std::lock_guard<std::mutex> lk(mu_);
+        for (auto& kv : ctxs_) hvrt_destroy(kv.second);
+        for (auto& kv : groups_) hvrt_group_destroy(kv.second);
+        ctxs_.clear();
+        groups_.clear();
+    }
+    ~ContextPool() { clear(); }
+
+private:
+    ContextPool() {
+        if (const char* e = std::getenv("HVRT_CONTEXT_CACHE")) enabled_ = std::atoi(e) != 0;
+    }
+    std::mutex mu_;
+    std::multimap<int, hvrt_ctx*> ctxs_;
+    std::multimap<std::string, hvrt_group*> groups_;
+    bool enabled_ = true;
+};
+
+}  // namespace
+
+void HipScene::releaseCachedContexts() { ContextPool::get().clear(); }
+
 HipScene::HipScene(int device_id) {
-    // which devices: HVRT_DEVICES ("0,1,2", "all"), else device_id alone -- a group is only formed when asked for or
-    // when listing several; a device may be listed twice (two contexts on one GPU, the copy transport)
+    // which devices: HVRT_DEVICES ("0,1,2", "all") asks for a group; unset, the scene lives on device_id alone, however
+    // many GPUs are visible (one process per GPU -- rank r constructing HipScene(r) -- is the other multi-GPU model and
+    // must get exactly its device).  A device may be listed twice (two contexts on one GPU, the copy transport).
     std::vector<int> ids;
     if (const char* e = std::getenv("HVRT_DEVICES")) {
         const std::string v(e);
@@ -50,29 +118,49 @@ HipScene::HipScene(int device_id) {
                 p = q + 1;
             }
         }
-    } else if (hvrt_device_count() > 1) {
-        const int n = hvrt_device_count();
-        for (int i = 0; i < n; ++i) ids.push_back(i);
     }
+    if (ids.empty()) ids.push_back(device_id);
     if (const char* e = std::getenv("HVRT_GROUP_MIN_PIXELS")) group_min_pixels_ = (size_t)std::strtoull(e, nullptr, 10);
+    ContextPool& pool = ContextPool::get();
     if (ids.size() > 1) {
-        if (hvrt_group_create(&group_, ids.data(), (int)ids.size()) != HVRT_OK)
-            throw std::runtime_error(std::string("hvrt_group_create: ") + hvrt_group_last_error(nullptr));
+        for (int id : ids) pool_key_ += std::to_string(id) + ",";
+        group_ = pool.takeGroup(pool_key_);
+        if (group_) {
+            for (int i = 0; i < hvrt_group_size(group_); ++i) (void)hvrt_clear_scene(hvrt_group_member(group_, i));
+            LOG_INFO("[HipVoxelGrid] scene spans {} devices ({} transport; group taken from the pool)", ids.size(), hvrt_group_transport(group_));
+        } else {
+            if (hvrt_group_create(&group_, ids.data(), (int)ids.size()) != HVRT_OK)
+                throw std::runtime_error(std::string("hvrt_group_create: ") + hvrt_group_last_error(nullptr));
+            hvrt_group_timings gt{};
+            hvrt_group_get_timings(group_, &gt);
+            LOG_INFO("[HipVoxelGrid] scene spans {} devices ({} transport; group created in {:.1f} ms)", ids.size(),
+                     hvrt_group_transport(group_), gt.create_ms);
+        }
         ctx_ = hvrt_group_member(group_, 0);
-        LOG_INFO("[HipVoxelGrid] scene spans {} devices ({} transport)", ids.size(), hvrt_group_transport(group_));
+        device_ = ids[0];
         return;
     }
-    if (hvrt_create(&ctx_, ids.empty() ? device_id : ids[0]) != HVRT_OK) raise(nullptr, "hvrt_create");
+    device_ = ids[0];
+    ctx_ = pool.takeContext(device_);
+    if (ctx_) { (void)hvrt_clear_scene(ctx_); return; }
+    if (hvrt_create(&ctx_, device_) != HVRT_OK) raise(nullptr, "hvrt_create");
 }
 
 HipScene::~HipScene() {
-    if (group_) hvrt_group_destroy(group_);     // owns the contexts
-    else hvrt_destroy(ctx_);
+    if (group_) ContextPool::get().give(pool_key_, group_);     // owns the contexts
+    else if (ctx_) ContextPool::get().give(device_, ctx_);
 }
 
 void HipScene::replicate() {
-    if (group_ && hvrt_group_replicate_scene(group_) != HVRT_OK)
+    // (lazy: the other members receive the scene when the first frame large enough for the group is asked for --
+    // the reference's default 800x600 frame never is, and its flow builds a scene per image)
+    if (!group_ || replicated_) return;
+    if (hvrt_group_replicate_scene(group_) != HVRT_OK)
         throw std::runtime_error(std::string("hvrt_group_replicate_scene: ") + hvrt_group_last_error(group_));
+    replicated_ = true;
+    hvrt_group_timings gt{};
+    hvrt_group_get_timings(group_, &gt);
+    LOG_INFO("[HipVoxelGrid] scene replicated to {} devices in {:.1f} ms", hvrt_group_size(group_), gt.replicate_ms);
 }
 
 bool HipScene::spansDevices(int width, int height) const {
@@ -83,12 +171,13 @@ int HipScene::deviceCount() const { return group_ ? hvrt_group_size(group_) : 1;
 
 void HipScene::setTriangles(const std::vector<Triangle>& tris) {
     tris_ = tris;
+    replicated_ = false;
     ck(ctx_, hvrt_set_mesh(ctx_, tris.empty() ? nullptr : &tris[0].v0.x, (uint32_t)tris.size()), "hvrt_set_mesh");
 }
 
 void HipScene::buildGrid(int nx, int ny, int nz, const Vec3& mn, const Vec3& mx, const Vec3& vs) {
     ck(ctx_, hvrt_build_grid(ctx_, nx, ny, nz, &mn.x, &mx.x, &vs.x), "hvrt_build_grid");
-    replicate();
+    replicated_ = false;
 }
 
 void HipScene::computeBounds(const float* xyz, size_t n, Vec3& mn, Vec3& mx) {
@@ -126,7 +215,7 @@ void HipScene::setGrid(const VoxelGrid& g) {
     offsets[nvox] = (uint32_t)indices.size();
     ck(ctx_, hvrt_set_grid_csr(ctx_, g.nx, g.ny, g.nz, &g.minBound.x, &g.maxBound.x, &g.voxelSize.x, offsets.data(),
                                indices.empty() ? nullptr : indices.data()), "hvrt_set_grid_csr");
-    replicate();
+    replicated_ = false;
 }
 
 VoxelGrid HipScene::downloadGrid() const {
@@ -165,9 +254,12 @@ double HipScene::lastRenderMs() const {
 // --------------------------------------------------------------------------------- HipVoxelRayTracer
 
 HipVoxelRayTracer::HipVoxelRayTracer(const VoxelGrid& grid, int, int) : scene_(std::make_shared<HipScene>(0)) {
+    const auto t0 = std::chrono::steady_clock::now();
     LOG_INFO("[{}] Uploading voxel grid {}x{}x{} ({} triangles) to the GPU", getMethodName(), grid.nx, grid.ny, grid.nz,
              grid.triangles.size());
     scene_->setGrid(grid);
+    LOG_INFO("[{}] grid resident after {:.1f} ms", getMethodName(),
+             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 }
 
 HipVoxelRayTracer::HipVoxelRayTracer(std::shared_ptr<HipScene> scene) : scene_(std::move(scene)) {
@@ -184,22 +276,31 @@ std::vector<Vec3> HipVoxelRayTracer::render(const Camera& cam, int width, int he
     if (keep_hit_ids_) hit_ids_.assign((size_t)width * height, HVRT_MISS); else hit_ids_.clear();
     uint64_t counters[2] = { 0, 0 };
     uint64_t hits = 0;
-    if (scene_->spansDevices(width, height) && !keep_hit_ids_) {
-        // row tiles over every device of the scene, slabs gathered on the first (include/hvrt.h, group section)
+    double kernel_ms = 0.0;
+    if (scene_->spansDevices(width, height)) {
+        // row tiles over every device of the scene, each member copying its own tiles into `frame` (include/hvrt.h, group section)
+        scene_->replicate();
         LOG_INFO("[{}] Rendering {}x{} image on {} devices...", getMethodName(), width, height, scene_->deviceCount());
-        if (hvrt_group_render(scene_->group(), &fr, width, height, 1, 0, &frame[0].x, counters, &hits) != HVRT_OK)
+        if (hvrt_group_render(scene_->group(), &fr, width, height, 1, 0, &frame[0].x, keep_hit_ids_ ? hit_ids_.data() : nullptr,
+                              nullptr, counters, &hits) != HVRT_OK)
             throw std::runtime_error(std::string("hvrt_group_render: ") + hvrt_group_last_error(scene_->group()));
+        hvrt_group_timings gt{};
+        hvrt_group_get_timings(scene_->group(), &gt);
+        kernel_ms = gt.render_ms;
+        LOG_INFO("[{}] group render {:.3f} ms in all (longest traversal {:.3f} ms, longest copy-out {:.3f} ms)", getMethodName(),
+                 gt.total_ms, gt.render_ms, gt.download_ms);
     } else {
         LOG_INFO("[{}] Rendering {}x{} image...", getMethodName(), width, height);
         ck(scene_->handle(), hvrt_render(scene_->handle(), &fr, width, height, 1, 0, &frame[0].x,
                                          keep_hit_ids_ ? hit_ids_.data() : nullptr, nullptr, counters), "hvrt_render");
         ck(scene_->handle(), hvrt_last_hit_count(scene_->handle(), &hits), "hvrt_last_hit_count");
+        kernel_ms = scene_->lastRenderMs();
     }
     voxels_ = counters[0];
     tests_ = counters[1];
     const double total = (double)width * height;
     // same statistics lines as OctreeLikeRayTracer.cpp:57-65 (counted once per ray, not twice)
-    LOG_INFO("[{}] Rendering complete! kernel {:.3f} ms", getMethodName(), scene_->lastRenderMs());
+    LOG_INFO("[{}] Rendering complete! kernel {:.3f} ms", getMethodName(), kernel_ms);
     LOG_INFO("[{}] Ray hits: {} / {} ({:.1f}%)", getMethodName(), hits, (size_t)total, 100.0 * hits / total);
     LOG_INFO("[{}] Voxels traversed: {}, Avg per ray: {:.1f}", getMethodName(), voxels_, voxels_ / total);
     LOG_INFO("[{}] Triangle tests: {}, Avg per ray: {:.1f}", getMethodName(), tests_, tests_ / total);
@@ -231,7 +332,15 @@ std::vector<std::vector<unsigned char>> HipVoxelRayTracer::renderViewsRgb8(const
     return out;
 }
 
-void HipVoxelRayTracer::setNearestHit(bool on) { ck(scene_->handle(), hvrt_set_mode(scene_->handle(), on ? 1 : 0), "hvrt_set_mode"); }
+void HipVoxelRayTracer::setNearestHit(bool on) {
+    // (a group: every member, or the frame would be striped -- hvrt_group_render also hands member 0's mode on)
+    if (scene_->group()) {
+        if (hvrt_group_set_mode(scene_->group(), on ? 1 : 0) != HVRT_OK)
+            throw std::runtime_error(std::string("hvrt_group_set_mode: ") + hvrt_group_last_error(scene_->group()));
+    } else {
+        ck(scene_->handle(), hvrt_set_mode(scene_->handle(), on ? 1 : 0), "hvrt_set_mode");
+    }
+}
 
 std::vector<RayHit> HipVoxelRayTracer::traceRays(const std::vector<Ray>& rays) {
     const size_t n = rays.size();

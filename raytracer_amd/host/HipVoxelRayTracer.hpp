@@ -21,10 +21,12 @@ struct hvrt_group;
 
 // A scene resident on the GPU(s): triangles + CSR grid.  Shared by tracers so that TraceImageMultiView's
 // three views (TraceImages.cpp:77-119) reuse one upload / one build.
-// Devices: HVRT_DEVICES in the environment lists them ("0,1,2,3", or "all"); unset, a scene lives on device_id alone
-// when the machine has one GPU and on every visible GPU otherwise.  With more than one, the scene is built on the
-// first and replicated (hvrt_group_replicate_scene), and frames of at least HVRT_GROUP_MIN_PIXELS pixels (default
-// 2^22) are traced by all of them (hvrt_group_render); smaller frames, batched views and single rays stay on the first.
+// Devices: a scene lives on device_id alone unless HVRT_DEVICES in the environment lists several ("0,1,2,3", or "all")
+// -- a device group is opt-in: one process per GPU, rank r constructing HipScene(r), is the other multi-GPU model and
+// gets exactly its device.  With a group the scene is built on the first device, replicated when the first frame of at
+// least HVRT_GROUP_MIN_PIXELS pixels (default 2^22) is asked for (hvrt_group_replicate_scene), and such frames are traced
+// by all members, each copying its own row tiles into the caller's frame (hvrt_group_render); smaller frames, batched
+// views and single rays stay on the first device.  Contexts and groups are pooled per process (see the .cpp).
 class HipScene {
 public:
     explicit HipScene(int device_id = 0);
@@ -45,6 +47,9 @@ public:
     // Copy the GPU-built CSR back into the reference's container (voxels[x][y][z] + triangle_indices).
     VoxelGrid downloadGrid() const;
 
+    // Destroys the idle contexts / groups the process-wide pool holds (they are otherwise kept until exit).
+    static void releaseCachedContexts();
+
     hvrt_ctx* handle() const { return ctx_; }
     // the device group when the scene spans several GPUs (nullptr otherwise), and whether a frame of this size uses it
     hvrt_group* group() const { return group_; }
@@ -53,10 +58,14 @@ public:
     double lastBuildMs() const;
     double lastRenderMs() const;
 
+    void replicate();                  // group: hands the scene to the other members if they do not hold it yet
+
 private:
-    void replicate();                  // after every change of mesh or grid
     hvrt_ctx* ctx_ = nullptr;          // member 0 of the group when there is one
     hvrt_group* group_ = nullptr;
+    int device_ = 0;
+    std::string pool_key_;             // the group's device list
+    bool replicated_ = false;          // the other members hold the current mesh and grid
     size_t group_min_pixels_ = (size_t)1 << 22;
     std::vector<cg_datastructures::Triangle> tris_;   // host copy (downloadGrid returns them)
 };

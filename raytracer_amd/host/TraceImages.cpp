@@ -70,17 +70,25 @@ TraceImages::Loaded TraceImages::loadOrGenerate(const std::string& path, int nx,
         throw std::runtime_error("method '" + getRayTracingMethodName(method) +
                                  "' is the reference's CPU tracer, which this library does not contain; use HIP_VOXEL");
     Loaded l;
+    auto t0 = std::chrono::steady_clock::now();
     l.scene = std::make_shared<HipScene>(0);
+    lastPhases.context_ms = 1e3 * seconds_since(t0);
+    t0 = std::chrono::steady_clock::now();
     if (ext == ".voxgrid") {
         LOG_INFO("Loading pre-saved voxel grid from: {}", path);
         l.grid = VoxelGrid::loadFromFile(path);
+        lastPhases.load_ms = 1e3 * seconds_since(t0);
+        t0 = std::chrono::steady_clock::now();
         l.scene->setGrid(l.grid);
     } else {
         LOG_INFO("Processing STL file: {}", path);
         stl_reader::StlMesh<float, unsigned int> mesh(path);
         LOG_INFO("Loaded mesh with {} triangles", mesh.num_tris());
+        lastPhases.load_ms = 1e3 * seconds_since(t0);
+        t0 = std::chrono::steady_clock::now();
         l.grid = buildSceneOnGpu(mesh, nx, ny, nz, *l.scene);
     }
+    lastPhases.build_ms = 1e3 * seconds_since(t0);
     return l;
 }
 
@@ -124,8 +132,11 @@ void TraceImages::renderAndSave(Loaded& l, const Camera& cam, const std::string&
     lastPixels = tracer.render(cam, imageWidth, imageHeight);
     lastHitIds = tracer.lastHitIds();
     const double s = seconds_since(t0);
+    lastPhases.render_ms = 1e3 * s;
     LOG_INFO("Rendered {} pixels in {:.3f}s ({:.0f} rays/sec)", lastPixels.size(), s, (imageWidth * (double)imageHeight) / s);
+    t0 = std::chrono::steady_clock::now();
     SaveImage(outputDirectory + filename, lastPixels, imageWidth, imageHeight);
+    lastPhases.save_ms = 1e3 * seconds_since(t0);
 }
 
 void TraceImages::TraceImage(std::string gridFileLocation, std::string outputFileName, RayTracingMethod method) {
@@ -133,11 +144,15 @@ void TraceImages::TraceImage(std::string gridFileLocation, std::string outputFil
     LOG_INFO("Input: {} | Output: {} | Method: {}", gridFileLocation, outputFileName, getRayTracingMethodName(method));
     auto t0 = std::chrono::steady_clock::now();
     lastOk = false;
+    lastPhases = Phases{};
     try {
         Loaded l = loadOrGenerate(gridFileLocation, gridResolution, gridResolution, gridResolution, method);
         LOG_INFO("Voxel grid generated with size: ({:.6f}, {:.6f}, {:.6f})", l.grid.voxelSize.x, l.grid.voxelSize.y, l.grid.voxelSize.z);
         renderAndSave(l, setupCamera(l.grid), outputFileName, method);
+        lastPhases.total_ms = 1e3 * seconds_since(t0);
         LOG_INFO("Success! Generated {} in {:.3f}s", outputFileName, seconds_since(t0));
+        LOG_INFO("Phases (ms): context {:.2f} | read {:.2f} | upload + build {:.2f} | render + copy {:.2f} | save {:.2f}", lastPhases.context_ms,
+                 lastPhases.load_ms, lastPhases.build_ms, lastPhases.render_ms, lastPhases.save_ms);
         lastOk = true;
     } catch (const std::exception& e) {
         // as the reference: log and carry on with the next image (TraceImages.cpp:69-74)
@@ -149,6 +164,7 @@ void TraceImages::TraceImageMultiView(std::string gridFileLocation, std::string 
     LOG_INFO("========== Starting multi-view image generation ==========");
     auto t0 = std::chrono::steady_clock::now();
     lastOk = false;
+    lastPhases = Phases{};
     try {
         // the grid is built once and stays resident for all three views
         Loaded l = loadOrGenerate(gridFileLocation, gridResolution, gridResolution, gridResolution, method);
@@ -164,9 +180,13 @@ void TraceImages::TraceImageMultiView(std::string gridFileLocation, std::string 
         const auto frames = tracer.renderViewsRgb8(cams, imageWidth, imageHeight);
         lastPixels.clear();
         lastHitIds = tracer.lastHitIds();
+        lastPhases.render_ms = 1e3 * seconds_since(tv);
         LOG_INFO("{} views rendered in {:.3f}s", frames.size(), seconds_since(tv));
+        tv = std::chrono::steady_clock::now();
         for (size_t i = 0; i < frames.size(); ++i)
             SaveImageBytes(outputDirectory + stem + views[i].second + ext, frames[i].data(), imageWidth, imageHeight);
+        lastPhases.save_ms = 1e3 * seconds_since(tv);
+        lastPhases.total_ms = 1e3 * seconds_since(t0);
         LOG_INFO("Success! Generated all views in {:.3f}s", seconds_since(t0));
         lastOk = true;
     } catch (const std::exception& e) {

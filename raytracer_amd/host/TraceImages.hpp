@@ -45,6 +45,11 @@ public:
     std::vector<unsigned int> lastHitIds;   // of the last image; single-view renders fetch them only if keepHitIds
     bool keepHitIds = false;
     bool lastOk = false;
+    // where the last TraceImage / TraceImageMultiView call spent its time, host clock, milliseconds (the reference logs
+    // grid generation and rendering, TraceImages.cpp:38-44, 54-67): taking a context (created, or from the process-wide
+    // pool), reading the file, upload + voxel build, render() incl. the copy to the host, writing the image
+    struct Phases { double context_ms = 0, load_ms = 0, build_ms = 0, render_ms = 0, save_ms = 0, total_ms = 0; };
+    Phases lastPhases;
 
     // the factory seam (TraceImages.cpp:464-484), public here so that tests can reach it
     std::unique_ptr<IRayTracer> createRayTracer(VoxelGrid& voxelGrid, RayTracingMethod method);

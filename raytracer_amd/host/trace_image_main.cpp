@@ -2,6 +2,9 @@
 // Windows paths, RayTracer.cpp:8-44; this takes them as arguments).
 //   trace_image render <in.stl|in.voxgrid> <out.png|.ppm> [--method hip|voxel_dda|art|octree] [--multiview]
 //                      [--grid N] [--size WxH] [--outdir DIR] [--dump-raw FILE] [--nearest] [--quiet]
+//                      [--repeat N] [--phases FILE]
+//                      (--repeat: the whole TraceImage call N times, as the reference's main() does for its list of models,
+//                       RayTracer.cpp:20-40; --phases: one JSON line of per-phase milliseconds per call)
 //   trace_image stl-info <in.stl> <out.bin>        (CPU only: vertex / triangle numbering of the loader)
 //   trace_image save-voxgrid <in.stl> <out.voxgrid> [--grid N]
 #include <cstdio>
@@ -23,8 +26,8 @@ int main(int argc, char** argv) {
     const std::string cmd = argv[1], in = argv[2], out = argv[3];
     RayTracingMethod method = RayTracingMethod::HIP_VOXEL;
     bool multiview = false, nearest = false;
-    int grid = 50, W = 800, H = 600;
-    std::string outdir, dump;
+    int grid = 50, W = 800, H = 600, repeat = 1;
+    std::string outdir, dump, phases;
     for (int i = 4; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> std::string { if (i + 1 >= argc) { usage(); std::exit(2); } return argv[++i]; };
@@ -41,6 +44,8 @@ int main(int argc, char** argv) {
         else if (a == "--outdir") outdir = next();
         else if (a == "--dump-raw") dump = next();
         else if (a == "--nearest") nearest = true;
+        else if (a == "--repeat") repeat = std::atoi(next().c_str());
+        else if (a == "--phases") phases = next();
         else if (a == "--quiet") Logger::setLevel(hvrt_log::ERROR);
         else return usage();
     }
@@ -71,8 +76,16 @@ int main(int argc, char** argv) {
             ti.outputDirectory = outdir;
             ti.nearestHit = nearest;
             ti.keepHitIds = !dump.empty();      // the raw dump holds the hit-id image
-            if (multiview) ti.TraceImageMultiView(in, out, method);
-            else ti.TraceImage(in, out, method);
+            std::ofstream pf;
+            if (!phases.empty()) pf.open(phases);
+            for (int r = 0; r < (repeat < 1 ? 1 : repeat); ++r) {
+                if (multiview) ti.TraceImageMultiView(in, out, method);
+                else ti.TraceImage(in, out, method);
+                if (!ti.lastOk) break;
+                const TraceImages::Phases& p = ti.lastPhases;
+                if (pf) pf << "{\"call\": " << r << ", \"context_ms\": " << p.context_ms << ", \"load_ms\": " << p.load_ms << ", \"build_ms\": " << p.build_ms
+                           << ", \"render_ms\": " << p.render_ms << ", \"save_ms\": " << p.save_ms << ", \"total_ms\": " << p.total_ms << "}\n";
+            }
             if (ti.lastOk && !dump.empty()) {
                 std::ofstream f(dump, std::ios::binary);
                 f.write((const char*)ti.lastPixels.data(), (std::streamsize)(ti.lastPixels.size() * 12));

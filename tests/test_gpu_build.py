@@ -49,6 +49,23 @@ def build_both(ctx, tris, dims, points=None):
     return info, off, idx, mn, mx, vs
 
 
+def _fresh(env=None):
+    import os
+    import raytracer_amd as ra
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        return ra.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
 FIXTURES = {
     "cube_on_voxel_planes": lambda: (meshgen.box(), (8, 8, 8)),
     "sphere_16": lambda: (meshgen.cube_sphere(12), (16, 16, 16)),
@@ -84,6 +101,27 @@ def test_long_lists_all_sort_tiers(ctx):
     assert 4096 < info.max_list <= 32768
     info, *_ = build_both(ctx, meshgen.skewed_statue(30, 60), (32, 32, 32))
     assert 32 < info.max_list <= 4096
+
+
+def test_a_list_beyond_16_bits_rejects_the_narrow_counters():
+    """Four voxels of this scene hold more than 65 535 triangles (89 060 in the longest list).  A fresh context counts
+    into 16-bit counters first: the carry shows as two differing totals, the front of the build is issued again with
+    32-bit counters -- seen here as the context's counter width going from 16 to 32 for good -- and the CSR is the
+    oracle's bit for bit, as it is on a context that never used the narrow counters (HVRT_BUILD_NARROW=0)."""
+    tris = meshgen.skewed_statue(12, 420)
+    for env, first in (({}, 16), ({"HVRT_BUILD_NARROW": "0"}, 32)):
+        c = _fresh(env)
+        try:
+            assert c.counter_width() == first
+            info, *_ = build_both(c, meshgen.cube_sphere(10), (16, 16, 16))       # short lists: the width stays
+            assert c.counter_width() == first
+            info, *_ = build_both(c, tris, (8, 8, 8))
+            assert info.max_list > 65535
+            assert c.counter_width() == 32
+            info, *_ = build_both(c, tris, (8, 8, 8))                             # and again, now wide from the start
+            assert info.max_list > 65535 and c.counter_width() == 32
+        finally:
+            c.close()
 
 
 def test_big_triangles_take_the_wave_cooperative_path(ctx):
@@ -224,6 +262,15 @@ def test_config3_like_skewed_full_size_csr(ctx):
     assert info.max_list > 1000 and info.n_refs > 15_000_000
 
 
+def test_config3_bench_mesh_full_size_csr(ctx):
+    """BASELINE config 3 on the very mesh bench.py --workload c3 times (cube-sphere N = 913 = 10 002 828
+    triangles, plus the dense patch; 512^3): CSR and distance field compared in full."""
+    tris = meshgen.skewed_statue(913, 1100)
+    assert tris.shape[0] == 10_002_828 + 2 * 1100 * 1100
+    info, off, idx, mn, mx, vs = build_both(ctx, tris, (512, 512, 512))
+    assert info.max_list > 1000 and info.n_refs > 25_000_000
+
+
 def test_config5_full_size_csr(ctx):
     """BASELINE config 5: 49 988 172 triangles into 1024^3 (build only).  Offsets (4.3 GB) and indices compared
     bit for bit with the oracle; the distance field checked through the property that defines it: 0 exactly
@@ -258,23 +305,6 @@ def test_config5_full_size_csr(ctx):
     want = np.where(m == 255, 255, m + 1).astype(np.uint8)
     free = d != 0
     assert np.array_equal(d[free], want[free])
-
-
-def _fresh(env=None):
-    import os
-    import raytracer_amd as ra
-    old = {}
-    for k, v in (env or {}).items():
-        old[k] = os.environ.get(k)
-        os.environ[k] = v
-    try:
-        return ra.Context(0)
-    finally:
-        for k, v in old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
 
 
 @pytest.mark.parametrize("reuse", ["1", "0"])

@@ -551,12 +551,57 @@ def test_config3_like_full_size_render_rows_nearest_hit_mode(ctx):
     _rows_against_oracle(ctx, meshgen.skewed_statue(289, 2100), 512, W, H, rows, launches=3, mode=1)
 
 
+def test_config3_bench_mesh_full_size_render_rows(ctx):
+    """BASELINE config 3 on the very mesh bench.py --workload c3 times (cube-sphere N = 913 plus the dense
+    patch, 12.4 M triangles, 512^3, 3840x2160): every 24th row and every 2nd row across the patch, third launch."""
+    W, H = 3840, 2160
+    rows = sorted(set(range(3, H, 24)) | set(range(1000, 1160, 2)))
+    _rows_against_oracle(ctx, meshgen.skewed_statue(913, 1100), 512, W, H, rows, launches=3)
+
+
 def test_config4_8k_16spp_rows(ctx):
-    """BASELINE config 4: the config 2 scene at 7680x4320 with 16 jittered samples per pixel; 24 rows against
-    the oracle (colour is the mean of 16 samples summed in sample order; hit id / t are sample 0's)."""
+    """BASELINE config 4: the config 2 scene at 7680x4320 with 16 jittered samples per pixel; every 16th row (270 rows,
+    33 M rays) against the oracle (colour is the mean of 16 samples summed in sample order; hit id / t are sample 0's)."""
     W, H = 7680, 4320
-    rows = list(range(7, H, 180))
+    rows = list(range(7, H, 16))
     _rows_against_oracle(ctx, meshgen.cube_sphere(289), 256, W, H, rows, spp=16, seed=1)
+
+
+SWITCHES = [{"HVRT_WARMUP": "0"}, {"HVRT_TILE_SPLIT": "0"}, {"HVRT_TILE_ORDER": "0"}, {"HVRT_SPLIT_WAIT": "0"},
+            {"HVRT_TILE_ABORT_US": "0"}, {"HVRT_HISTORY_MAX_DEG": "0"}, {"HVRT_WARMUP": "0", "HVRT_TILE_ABORT_US": "1"}]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_render_under_every_scheduling_switch(monkeypatch, env):
+    """The environment switches that change how a frame is scheduled (never what it is): a fresh context per setting,
+    three launches per view so that the first-launch, ordered and split paths all run, frames bit for bit the oracle's.
+    HVRT_WARMUP=0 is the case round 2's last fix was for (the split kernel's report word on a context whose queue scratch
+    no warm-up launch had touched)."""
+    import raytracer_amd as ra
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    own = ra.Context(0)
+    try:
+        for name, size in (("skewed_long_lists", (1280, 720)), ("sphere_50_default_res", (800, 600)), ("slivers", (320, 240))):
+            gen, dims, _ = SCENES[name]
+            W, H = size
+            tris = gen()
+            sc, mn, mx = setup_scene(own, tris, dims)
+            for view in ("front", "side"):
+                fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view, aspect=W / H))
+                exp = sc.render(fr, W, H, threads=16)
+                for _ in range(3):
+                    assert_frames_equal(own.render(fr, W, H), exp)
+                # rgb alone: the two-launch path of hvrt_render (frames of 2^21 pixels and more take it)
+            if name == "skewed_long_lists":
+                W, H = 2048, 1100
+                fr = capi.make_camera_frame(*capi.default_camera(mn, mx, "front", aspect=W / H))
+                exp = sc.render(fr, W, H, threads=16)
+                for _ in range(3):
+                    rgb, none_h, none_t, cnt = own.render(fr, W, H, want_hit=False, want_t=False)
+                    assert np.array_equal(rgb.view(np.uint32), exp[0].view(np.uint32)) and np.array_equal(cnt, exp[3])
+    finally:
+        own.close()
 
 
 @pytest.mark.parametrize("name", ["sphere_16", "slivers", "skewed_long_lists"])

@@ -218,5 +218,49 @@ def test_trace_image_over_a_device_group(tmp_path):
     p = subprocess.run([EXE, "render", stl, "three.ppm", "--outdir", out, "--size", "640x360", "--grid", "32"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
-    assert "spans 3 devices (copy transport)" in p.stdout + p.stderr and "on 3 devices" in p.stdout + p.stderr
+    log = p.stdout + p.stderr
+    assert "spans 3 devices (copy transport" in log and "on 3 devices" in log and "scene replicated to 3 devices" in log
     assert open(tmp_path / "one.ppm", "rb").read() == open(tmp_path / "three.ppm", "rb").read()
+
+
+@pytest.mark.gpu
+def test_trace_image_group_keeps_mode_and_hit_ids(tmp_path):
+    """--nearest with the hit-id image kept, over three members: byte for byte one device's frame and ids (round 2:
+    the mode reached member 0 only, and keepHitIds fell back to one device)."""
+    stl = os.path.join(G, "fixture_binary.stl")
+    out = str(tmp_path) + "/"
+    one, three = str(tmp_path / "one.bin"), str(tmp_path / "three.bin")
+    run("render", stl, "one.ppm", "--outdir", out, "--size", "640x360", "--grid", "32", "--nearest", "--dump-raw", one, "--quiet")
+    run("render", stl, "ref.ppm", "--outdir", out, "--size", "640x360", "--grid", "32", "--quiet")
+    env = dict(os.environ, HVRT_DEVICES="0,0,0", HVRT_GROUP_MIN_PIXELS="1")
+    p = subprocess.run([EXE, "render", stl, "three.ppm", "--outdir", out, "--size", "640x360", "--grid", "32", "--nearest",
+                        "--dump-raw", three], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "on 3 devices" in p.stdout + p.stderr
+    assert open(one, "rb").read() == open(three, "rb").read()
+    assert open(tmp_path / "one.ppm", "rb").read() == open(tmp_path / "three.ppm", "rb").read()
+    assert open(tmp_path / "one.ppm", "rb").read() != open(tmp_path / "ref.ppm", "rb").read()      # the modes differ here
+
+
+@pytest.mark.gpu
+def test_a_tracer_per_image_reuses_pooled_contexts(tmp_path):
+    """The reference's flow makes a tracer (here: a scene, a context, with HVRT_DEVICES a whole group) per image.  The
+    second and third image of a process take theirs from the pool: no second hvrt_create / hvrt_group_create, the scene
+    is replicated again (it is a new scene), and every image is the same file."""
+    import json
+    stl = os.path.join(G, "fixture_binary.stl")
+    out = str(tmp_path) + "/"
+    for env_extra, tag in (({}, "one"), ({"HVRT_DEVICES": "0,0,0,0", "HVRT_GROUP_MIN_PIXELS": "1"}, "four")):
+        ph = str(tmp_path / f"{tag}.jsonl")
+        p = subprocess.run([EXE, "render", stl, f"{tag}.ppm", "--outdir", out, "--size", "640x360", "--grid", "32", "--repeat", "3",
+                            "--phases", ph], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env_extra))
+        assert p.returncode == 0, p.stderr[-2000:]
+        log = p.stdout + p.stderr
+        calls = [json.loads(l) for l in open(ph)]
+        assert len(calls) == 3
+        # the first call pays the runtime's start-up; the later ones take a warm context in well under that
+        assert calls[1]["context_ms"] < 0.25 * calls[0]["context_ms"] and calls[2]["context_ms"] < 0.25 * calls[0]["context_ms"], calls
+        if tag == "four":
+            assert log.count("group created in") == 1 and log.count("group taken from the pool") == 2
+            assert log.count("scene replicated to 4 devices") == 3
+    assert open(tmp_path / "one.ppm", "rb").read() == open(tmp_path / "four.ppm", "rb").read()
