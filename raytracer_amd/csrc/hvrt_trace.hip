@@ -60,32 +60,48 @@ __device__ __forceinline__ V3 normalize(V3 v) {
 // on_hit(t) runs where the hit is established (nested ifs, not early returns + a flag tested by the caller): a
 // rejected test then skips straight to the loop's end through one exec-mask restore -- every mask operation in
 // this loop is an instruction of the CU's one scalar unit.
+// (ray_triangle_s: the same test given s = o - v0 instead of o and v0 -- the subtraction is the reference's own,
+// GeometryUtils.cpp:73, whoever performs it: where all rays of a wave share their origin and the record comes from the
+// wave's LDS window, s is the same number in every lane and is worked out once per record, not once per lane and test)
+// (dc: diagnostic builds only -- two counters for scripts/diag_counts.py)
+#if defined(HVRT_DIAG) && (HVRT_DIAG == 25 || HVRT_DIAG == 26)
+#define HVRT_DIAG_STAGE(n, slot) if (dc && (HVRT_DIAG == (n)) && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) dc[slot] += 64;
+#else
+#define HVRT_DIAG_STAGE(n, slot)
+#endif
 template <class OnHit>
-__device__ __forceinline__ void ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, OnHit on_hit) {
+__device__ __forceinline__ void ray_triangle_s(V3 s, V3 e1, V3 e2, V3 d, OnHit on_hit, uint32_t* dc = nullptr) {
+    (void)dc;
+    HVRT_DIAG_STAGE(25, 0)      // 25: wave-level tests | of them, those in which some lane goes on to v
     V3 p = cross(d, e2);
     float det = dot(e1, p);
-    V3 s = sub(o, v0);
     float su = dot(s, p);
     const float r = __builtin_amdgcn_rcpf(det);
     const float ua = su * r;
     // one exit for "parallel" (the reference's first test) and "u far outside": no branch sits between the
     // record's loads, so they are issued together instead of v0 waiting for the determinant
     if (!((det > -EPS && det < EPS) | (ua < -1e-3f) | (ua > 1.001f))) {
+        HVRT_DIAG_STAGE(25, 1)
         V3 q = cross(s, e1);
         float sv = dot(d, q);
         const float va = sv * r;
         if (!(va < -1e-3f || ua + va > 1.002f)) {
+            HVRT_DIAG_STAGE(26, 0)      // 26: wave-level tests that reach the exact divide | that hit
             float inv = 1.0f / det;   // == (float)(1.0 / (double)det): double rounding is innocuous for 53 >= 2*24+2
             float u = inv * su;
             if (!((u < 0.0f && fabsf(u) > EPS) || (u > 1.0f && fabsf(u - 1.0f) > EPS))) {
                 float v = inv * sv;
                 if (!((v < 0.0f && fabsf(v) > EPS) || (u + v > 1.0f && fabsf(u + v - 1.0f) > EPS))) {
                     float t = inv * dot(e2, q);
-                    if (t > EPS) on_hit(t);
+                    if (t > EPS) { HVRT_DIAG_STAGE(26, 1) on_hit(t); }
                 }
             }
         }
     }
+}
+template <class OnHit>
+__device__ __forceinline__ void ray_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d, OnHit on_hit) {
+    ray_triangle_s(sub(o, v0), e1, e2, d, on_hit);
 }
 
 // the mask of lanes for which b holds, straight from the compare (HIP's __ballot goes through an integer)
@@ -157,6 +173,11 @@ __device__ __forceinline__ int dec_where(lanemask m, int v) {
 // preB, c).  The run is speculative: the caller picks the far axis from a cheap estimate, OK decides exactly; when it
 // fails for any lane the state is rolled back and the general steps are taken.  On success the flat index and
 // the counters are brought up to date from the number of A steps (only rA is kept per step).
+#if defined(HVRT_DIAG) && HVRT_DIAG == 24   // steps of two-axis runs in which every lane steps ONE axis only | the other two-axis steps
+#define HVRT_DIAG24_HOOK if (any_lane(!(dA == 0u || dB == 0u)) == 0ull) r.nv += (uint32_t)k; else r.nt += (uint32_t)k;
+#else
+#define HVRT_DIAG24_HOOK
+#endif
 #define HVRT_TWO_AXIS_RUN(tmA, tdA, rA, fsA, tmB, tdB, fsB, OK, AFTER)                               \
     do {                                                                                             \
         const float saveA = tmA, saveB = tmB;                                                        \
@@ -172,6 +193,7 @@ __device__ __forceinline__ int dec_where(lanemask m, int v) {
         (void)preA; (void)preB;                                                                      \
         if (any_lane(!(OK)) == 0ull) {                                                               \
             const uint32_t dA = (uint32_t)(save_rA - rA), dB = (uint32_t)k - dA;                     \
+            HVRT_DIAG24_HOOK                                                                         \
             f += dA * fsA + dB * fsB;                                                                \
             last = c ? fsA : fsB;                                                                    \
             AFTER;                                                                                   \
@@ -454,6 +476,90 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
 // the bytes differs.  ABORT gives up for the whole wave at once (the clock is a scalar).
 constexpr uint32_t COOP_CHUNK = 21;     // entries per cooperative chunk: 63 lanes x 16 B = 21 records of 48 B
 
+// ---- tile-level rejection of list entries (k_render: all rays of a wave leave from one point) ---------------------
+// Measured on config 2 (make diag DIAG=25 / 27): of the 102 wave-level ray / triangle tests per ray slot, 0.6 get past the
+// first rejection in ANY lane, and 101 are rejected by every direction of the 8x8 tile on the same side of u with one
+// sign of the determinant.  Such an entry need not be tested by 64 lanes one after the other: with a common origin o the
+// reference's first rejection (GeometryUtils.cpp:64-78) depends on the ray only through two linear forms of the direction,
+//      det = e1 . (d x e2) = d . (e2 x e1) =: d . N          s . (d x e2) = d . (e2 x s) =: d . M        (s = o - v0)
+// and u = (d . M) / (d . N) is outside [0, 1] for every d of a convex set on which d . N keeps its sign as soon as
+// d . (M + m N) or d . (M - (1 + m) N) keeps the right sign there.  The set is the bounding box of the 64 lanes' actual
+// float directions (centre c, half extents h, worked out once per tile and sample: tile_box), over which a linear form
+// d . X ranges within c . X +- h . |X|.  So ONE lane per record decides for the whole tile, 21 records at a time.
+//
+// It must PROVE the reference's rejection for the floats the reference computes, not for the real numbers:
+//   * the reference's det and s . p differ from d . N and d . M (reals, d the lane's float direction) by at most
+//     7 u |e1| |e2| |d| and 7 u |s| |e2| |d|, u = 2^-24 (each component of p = d x e2 is off by <= 2 u |d| |e2|, a
+//     three-term dot adds <= 3 u |a| |b|);
+//   * N, M, the two dots and the sums below are computed here in fp32, another <= 20 u of the same magnitudes, and the
+//     box centre / half extents carry <= 2^-22 per component;
+//   * all of it is covered by slacks of 2^-16 |e1|_1 |e2|_1 and 2^-16 |s|_1 |e2|_1 (1-norms: upper bounds of the
+//     Euclidean ones) -- a thousand times the sum of the above -- plus 1e-30 against gradual underflow;
+//   * u is rejected with a margin of 2^-11 on either side, far more than the two roundings between s . p / det and the
+//     reference's u = inv_det * (s . p) and than its FLT_EPSILON tolerance: "(d . M) / (d . N) < -2^-11" implies
+//     "u < 0 && |u| > EPS", "> 1 + 2^-11" implies "u > 1 && |u - 1| > EPS";
+//   * every condition is a comparison that is false on NaN, so infinities and NaNs anywhere cull nothing; a tile with a
+//     non-finite direction component gets an infinite box.
+// An entry that is culled would have been rejected by every lane (hit / miss, t and the reference's counters are
+// untouched: those count list entries, not executed tests); an entry that is not culled is tested as before.
+constexpr float CULL_MARGIN = 4.8828125e-4f;     // 2^-11
+constexpr float CULL_SLACK = 1.52587890625e-5f;  // 2^-16
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_of(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+// min and max over the 64 lanes (all active, no NaNs), in every lane
+__device__ __forceinline__ void wave_minmax(float v, float& lo, float& hi) {
+    float a = v, b = v;
+    a = __builtin_fminf(a, dpp_f<0xB1>(a)); b = __builtin_fmaxf(b, dpp_f<0xB1>(b));      // quad_perm [1,0,3,2]
+    a = __builtin_fminf(a, dpp_f<0x4E>(a)); b = __builtin_fmaxf(b, dpp_f<0x4E>(b));      // quad_perm [2,3,0,1]
+    a = __builtin_fminf(a, dpp_f<0x141>(a)); b = __builtin_fmaxf(b, dpp_f<0x141>(b));    // row_half_mirror
+    a = __builtin_fminf(a, dpp_f<0x140>(a)); b = __builtin_fmaxf(b, dpp_f<0x140>(b));    // row_mirror
+    lo = __builtin_fminf(__builtin_fminf(lane_of(a, 0), lane_of(a, 16)), __builtin_fminf(lane_of(a, 32), lane_of(a, 48)));
+    hi = __builtin_fmaxf(__builtin_fmaxf(lane_of(b, 0), lane_of(b, 16)), __builtin_fmaxf(lane_of(b, 32), lane_of(b, 48)));
+}
+// The bounding box of the wave's 64 ray directions -> box[0] = centre, box[1] = half extents (LDS, read back by
+// cull_chunk).  Called by all 64 lanes, with or without a live ray (every lane has a direction).
+__device__ __forceinline__ void tile_box(V3 d, float4* __restrict__ box) {
+    const bool finite = any_lane(!(fabsf(d.x) <= FLT_MAX && fabsf(d.y) <= FLT_MAX && fabsf(d.z) <= FLT_MAX)) == 0ull;
+    float lx, hx, ly, hy, lz, hz;
+    wave_minmax(d.x, lx, hx); wave_minmax(d.y, ly, hy); wave_minmax(d.z, lz, hz);
+    const float pad = finite ? 4.76837158203125e-7f : __builtin_inff();       // 2^-21 per component: the roundings of centre and half extent
+    if (lane_now() == 0) {
+        box[0] = { 0.5f * lx + 0.5f * hx, 0.5f * ly + 0.5f * hy, 0.5f * lz + 0.5f * hz, 0.0f };
+        box[1] = { (0.5f * hx - 0.5f * lx) + pad, (0.5f * hy - 0.5f * ly) + pad, (0.5f * hz - 0.5f * lz) + pad, 0.0f };
+    }
+}
+// Which of the chunk's records (win[3 k .. 3 k + 2] = s, e1, e2 of record k, k < 21) every direction of the tile rejects:
+// lane k decides for record k; returns the mask of culled records.
+__device__ __forceinline__ uint32_t cull_chunk(const float4* __restrict__ win, int lane) {
+    const int k = lane < (int)COOP_CHUNK ? lane : (int)COOP_CHUNK - 1;
+    const float4* __restrict__ rk = win + 3 * k;
+    const float4 q0 = rk[0], q1 = rk[1];
+    const float e2z = reinterpret_cast<const float*>(rk + 2)[0];
+    const float4 bc = win[64], bh = win[65];
+    const V3 sv = { q0.x, q0.y, q0.z }, e1 = { q0.w, q1.x, q1.y }, e2 = { q1.z, q1.w, e2z };
+    const float l1e2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
+    const float slack_n = CULL_SLACK * (((fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z)) * l1e2) + 1e-30f;
+    const float slack_m = CULL_SLACK * (((fabsf(sv.x) + fabsf(sv.y)) + fabsf(sv.z)) * l1e2) + 1e-30f;
+    const V3 N = cross(e2, e1);
+    const float n0 = (bc.x * N.x + bc.y * N.y) + bc.z * N.z;
+    const float rn = (bh.x * fabsf(N.x) + bh.y * fabsf(N.y)) + bh.z * fabsf(N.z);
+    const V3 M = cross(e2, sv);
+    const float m0 = (bc.x * M.x + bc.y * M.y) + bc.z * M.z;
+    const float rm = (bh.x * fabsf(M.x) + bh.y * fabsf(M.y)) + bh.z * fabsf(M.z);
+    const float an0 = fabsf(n0);
+    const float sm0 = __uint_as_float(__float_as_uint(m0) ^ (__float_as_uint(n0) & 0x80000000u));      // m0 * sign(n0)
+    const bool one_sign = an0 - rn > slack_n;                       // d . N keeps n0's sign, and so does the reference's det
+    const float reach = an0 + rn;                                   // >= |d . N| anywhere in the box
+    // u < -margin everywhere:  sign * d . (M + margin N) <= sm0 + margin an0 + rm + margin rn
+    const bool below = (sm0 + rm) + CULL_MARGIN * reach < -(slack_m + slack_n);
+    // u > 1 + margin everywhere:  sign * d . (M - (1 + margin) N) >= sm0 - rm - (1 + margin) (an0 + rn)
+    const bool above = (sm0 - rm) - (1.0f + CULL_MARGIN) * reach > slack_m + 2.0f * slack_n;
+    return (uint32_t)any_lane(one_sign && (below || above)) & ((1u << COOP_CHUNK) - 1u);
+}
+
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
     // OR over the 64 lanes (all must be active): two quad swaps, the two row mirrors, then the four rows' values
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
@@ -637,8 +743,14 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 // has to test (an entry one lane skips was tested by that ray one voxel ago and missed, so testing it
                 // again changes nothing), reading each record from LDS at a wave-uniform address (a broadcast)
                 const int lane = lane_now();
-                const float4 A = sc.ref_rec[3ull * ubase + (uint32_t)lane];
+                float4 A = sc.ref_rec[3ull * ubase + (uint32_t)lane];
                 uint32_t um = wave_or(todo);
+                if (SAME_ORIGIN) {
+                    // every third lane holds (v0, e1.x) of a record: s = o - v0 takes v0's place (three subtractions for the
+                    // chunk's 21 records instead of three per lane and tested entry)
+                    constexpr lanemask V0_LANES = 0x9249249249249249ull;      // lanes 0, 3, 6, ...
+                    A.x = sel(V0_LANES, o.x - A.x, A.x); A.y = sel(V0_LANES, o.y - A.y, A.y); A.z = sel(V0_LANES, o.z - A.z, A.z);
+                }
 #ifdef HVRT_DIAG   // diagnostic build only: what the two counters mean depends on HVRT_DIAG (scripts/diag_counts.py)
                 if (COUNT && lane == 0) {
                     if (HVRT_DIAG == 11) r.nv += 64;                                    // cooperative chunks
@@ -648,8 +760,37 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 if (COUNT && HVRT_DIAG == 13) r.nt += (uint32_t)__builtin_popcount(todo);   // tests the lanes wanted
 #endif
                 win[lane] = A;
+                if (SAME_ORIGIN) {
+                    // entries that every direction of the tile rejects are not tested at all (see cull_chunk)
+#if defined(HVRT_DIAG) && HVRT_DIAG == 28   // wave-level tests culled | left
+                    const uint32_t culled = cull_chunk(win, lane);
+                    if (COUNT && lane == 0) { r.nv += 64 * (uint32_t)__builtin_popcount(um & culled); r.nt += 64 * (uint32_t)__builtin_popcount(um & ~culled); }
+                    um &= ~culled;
+#else
+                    if (um) um &= ~cull_chunk(win, lane);
+#endif
+                }
 #if defined(HVRT_ABLATE) && HVRT_ABLATE == 1      // 1 = lists fetched, no entry tested
                 um = 0;
+#endif
+#if defined(HVRT_DIAG) && HVRT_DIAG == 27   // wave-level tests | of them, those that EVERY direction of the tile rejects by the same side of u (all 64 lanes, with or without a live ray)
+                if (COUNT && SAME_ORIGIN) {
+                    uint32_t um2 = um;
+                    while (um2) {
+                        const int k = __builtin_ctz(um2);
+                        um2 &= um2 - 1u;
+                        const float4* __restrict__ rec = win + 3 * k;
+                        const float4 c0 = rec[0], c1 = rec[1];
+                        const float2 c2 = *reinterpret_cast<const float2*>(rec + 2);
+                        const V3 s_ = { c0.x, c0.y, c0.z }, e1_ = { c0.w, c1.x, c1.y }, e2_ = { c1.z, c1.w, c2.x };
+                        const V3 p_ = cross(d, e2_);
+                        const float det_ = dot(e1_, p_), su_ = dot(s_, p_);
+                        const float ua_ = su_ * __builtin_amdgcn_rcpf(det_);
+                        const bool one_sign = any_lane(!(det_ > EPS)) == 0ull || any_lane(!(det_ < -EPS)) == 0ull;
+                        const bool one_side = any_lane(!(ua_ < -2e-3f)) == 0ull || any_lane(!(ua_ > 1.002f)) == 0ull;
+                        if (lane == 0) { r.nv += 64; if (one_sign && one_side) r.nt += 64; }
+                    }
+                }
 #endif
                 if (work) {
                     while (um) {
@@ -658,9 +799,13 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                         const float4* __restrict__ rec = win + 3 * k;
                         const float4 c0 = rec[0], c1 = rec[1];
                         const float2 c2 = *reinterpret_cast<const float2*>(rec + 2);
-                        ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, o, d, [&](float t) {
-                            if (!NEAREST || t < r.t) { r.tri = __float_as_uint(c2.y); r.t = t; }
-                        });
+                        auto keep = [&](float t) { if (!NEAREST || t < r.t) { r.tri = __float_as_uint(c2.y); r.t = t; } };
+#if defined(HVRT_DIAG) && (HVRT_DIAG == 25 || HVRT_DIAG == 26)
+                        uint32_t dcs[2] = { 0, 0 };
+                        if (SAME_ORIGIN) { ray_triangle_s({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, d, keep, COUNT ? dcs : nullptr); r.nv += dcs[0]; r.nt += dcs[1]; } else
+#endif
+                        if (SAME_ORIGIN) ray_triangle_s({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, d, keep);
+                        else ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, o, d, keep);
                     }
                 }
             } else {
@@ -806,7 +951,10 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
         TraceResult r;
         // the wave-synchronous walk wants every lane of the wave in the call, with or without a ray (alive);
         // the per-lane walks are only ever called by lanes that have one
-        if constexpr (INLINE && RAYS == 64) r = trace_ray_wave<COUNT, NEAREST, ABORT, true>(sc, org, d, alive, win, wall0 + ra.abort_ticks * (s + 1));
+        if constexpr (INLINE && RAYS == 64) {
+            tile_box(d, win + 64);
+            r = trace_ray_wave<COUNT, NEAREST, ABORT, true>(sc, org, d, alive, win, wall0 + ra.abort_ticks * (s + 1));
+        }
         else r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, wall0 + ra.abort_ticks * (s + 1));
         if (ABORT && r.tri == HVRT_ABORTED) return false;
         const V3 c = shade(sc, r, org, v);
@@ -842,7 +990,7 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
 constexpr uint32_t RENDER_BLOCK_WAVES = HVRT_RENDER_BLOCK / 64;
 template <bool COUNT, bool INLINE, bool NEAREST, bool ABORT>
 __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArgs& ra) {
-    __shared__ float4 lds_win[RENDER_BLOCK_WAVES][64];     // per wave: the list chunk its lanes are testing (trace_ray_wave)
+    __shared__ float4 lds_win[RENDER_BLOCK_WAVES][66];     // per wave: the list chunk its lanes are testing (trace_ray_wave), [64..65] the tile's direction box
     // (the lane number is worked out where it is needed, lane_now(): a register held for it would be spilled)
     float4* const win = lds_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
