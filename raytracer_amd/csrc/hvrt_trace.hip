@@ -475,6 +475,9 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
 // Arithmetic, voxel sequence, test order and counters are trace_ray's (and so the reference's); only who fetches
 // the bytes differs.  ABORT gives up for the whole wave at once (the clock is a scalar).
 constexpr uint32_t COOP_CHUNK = 21;     // entries per cooperative chunk: 63 lanes x 16 B = 21 records of 48 B
+#ifndef HVRT_GROUP_SERIAL
+#define HVRT_GROUP_SERIAL 0
+#endif
 
 // ---- tile-level rejection of list entries (k_render: all rays of a wave leave from one point) ---------------------
 // Measured on config 2 (make diag DIAG=25 / 27): of the 102 wave-level ray / triangle tests per ray slot, 0.6 get past the
@@ -531,15 +534,16 @@ __device__ __forceinline__ void tile_box(V3 d, float4* __restrict__ box) {
         box[1] = { (0.5f * hx - 0.5f * lx) + pad, (0.5f * hy - 0.5f * ly) + pad, (0.5f * hz - 0.5f * lz) + pad, 0.0f };
     }
 }
-// Which of the chunk's records (win[3 k .. 3 k + 2] = s, e1, e2 of record k, k < 21) every direction of the tile rejects:
-// lane k decides for record k; returns the mask of culled records.
-__device__ __forceinline__ uint32_t cull_chunk(const float4* __restrict__ win, int lane) {
+// Which of the chunk's records (win[3 k .. 3 k + 2] = v0, e1, e2 of record k, k < 21) every direction of the tile rejects:
+// lane k decides for record k (s = o - v0 is the reference's own subtraction, GeometryUtils.cpp:73, done once per record
+// here); returns the mask of culled records.
+__device__ __forceinline__ uint32_t cull_chunk(const float4* __restrict__ win, int lane, V3 o) {
     const int k = lane < (int)COOP_CHUNK ? lane : (int)COOP_CHUNK - 1;
     const float4* __restrict__ rk = win + 3 * k;
     const float4 q0 = rk[0], q1 = rk[1];
     const float e2z = reinterpret_cast<const float*>(rk + 2)[0];
     const float4 bc = win[64], bh = win[65];
-    const V3 sv = { q0.x, q0.y, q0.z }, e1 = { q0.w, q1.x, q1.y }, e2 = { q1.z, q1.w, e2z };
+    const V3 sv = sub(o, { q0.x, q0.y, q0.z }), e1 = { q0.w, q1.x, q1.y }, e2 = { q1.z, q1.w, e2z };
     const float l1e2 = (fabsf(e2.x) + fabsf(e2.y)) + fabsf(e2.z);
     const float slack_n = CULL_SLACK * (((fabsf(e1.x) + fabsf(e1.y)) + fabsf(e1.z)) * l1e2) + 1e-30f;
     const float slack_m = CULL_SLACK * (((fabsf(sv.x) + fabsf(sv.y)) + fabsf(sv.z)) * l1e2) + 1e-30f;
@@ -707,16 +711,32 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         if (alive) { const uint32_t* pv = offs + f; b0 = pv[0]; b1 = pv[1]; }
 #endif
         const bool entered = last != 0u;
-        // the face through which the voxel was entered (word offset of its bit array: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z,
-        // 5 +z neighbour), from the last step's increment -- the walking direction is in the increments' signs, so
-        // nothing but `last` is kept for it.  A surviving x step implies nx > 1, so the axes are told apart in this
-        // order with their extent (in a 1-wide grid fsx == fsy or fsy == fsz)
-        const uint32_t face = sel(any_lane(last == fsx) & (g.nx > 1 ? ~0ull : 0ull), sel(any_lane(fsx == 1u), 0u, fw),
-                                  sel(any_lane(last == fsy) & (g.ny > 1 ? ~0ull : 0ull), sel(any_lane(fsy == (uint32_t)g.nx), 2u * fw, 3u * fw),
-                                      sel(any_lane(fsz == plane), 4u * fw, 5u * fw)));
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
         const uint32_t n = b1 - b0;       // 0 for lanes without a ray
         uint32_t c = 0;
+        // Which entries of the chunk at `base` this lane has to test: all `left` of them (at most COOP_CHUNK) but those
+        // that are also listed in the voxel the ray came from -- it tested them there, one step ago, and missed.
+        // The face through which the voxel was entered (word offset of its bit array: 0 -x, 1 +x, 2 -y, 3 +y, 4 -z,
+        // 5 +z neighbour) comes from the last step's increment -- the walking direction is in the increments' signs, so
+        // nothing but `last` is kept for it.  A surviving x step implies nx > 1, so the axes are told apart in this
+        // order with their extent (in a 1-wide grid fsx == fsy or fsy == fsz).
+        // (Worked out only where a test may really run: the tile-level rejection below leaves nothing of most chunks.)
+        auto todo_of = [&](uint32_t base, bool work) -> uint32_t {
+            uint32_t todo = 0;
+            if (work) {
+                uint32_t skip = 0;
+                if (entered) {
+                    const uint32_t face = sel(any_lane(last == fsx) & (g.nx > 1 ? ~0ull : 0ull), sel(any_lane(fsx == 1u), 0u, fw),
+                                              sel(any_lane(last == fsy) & (g.ny > 1 ? ~0ull : 0ull), sel(any_lane(fsy == (uint32_t)g.nx), 2u * fw, 3u * fw),
+                                                  sel(any_lane(fsz == plane), 4u * fw, 5u * fw)));
+                    const uint32_t* __restrict__ fb = sc.face_bits + (face + (base >> 5));
+                    skip = __builtin_amdgcn_alignbit(fb[1], fb[0], base & 31u);
+                }
+                const uint32_t left = n - c;
+                todo = ~skip & (left >= COOP_CHUNK ? ((1u << COOP_CHUNK) - 1u) : ((1u << left) - 1u));
+            }
+            return todo;
+        };
         for (;;) {
             const bool work = c < n;
             const unsigned long long wm = any_lane(work);
@@ -726,73 +746,43 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 if (any_lane(work && c != 0u) != 0ull && wall_clock64() > (unsigned long long)deadline) { r.tri = HVRT_ABORTED; return r; }
             }
             const uint32_t base = b0 + c;
-            uint32_t todo = 0;
-            if (work) {
-                uint32_t skip = 0;
-                if (entered) {
-                    const uint32_t* __restrict__ fb = sc.face_bits + (face + (base >> 5));
-                    skip = __builtin_amdgcn_alignbit(fb[1], fb[0], base & 31u);
-                }
-                const uint32_t left = n - c;
-                todo = ~skip & (left >= COOP_CHUNK ? ((1u << COOP_CHUNK) - 1u) : ((1u << left) - 1u));
-            }
-            const uint32_t ubase = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(wm));
-            if (any_lane(work && base != ubase) == 0ull) {
+            const int first = __builtin_ctzll(wm);
+            const uint32_t ubase = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+            // SAME_ORIGIN: the lanes that stand in the first working lane's voxel are served together; those in other voxels
+            // wait for a later round of this loop (HVRT_GROUP_SERIAL)
+            const bool mine = work && base == ubase;
+            if ((SAME_ORIGIN && HVRT_GROUP_SERIAL) || any_lane(work && base != ubase) == 0ull) {
                 // every lane with work is in this chunk of this list (same voxel, so same list length): one coalesced
                 // fetch for the wave, parked in the wave's LDS window; every lane then tests the entries that ANY lane
                 // has to test (an entry one lane skips was tested by that ray one voxel ago and missed, so testing it
                 // again changes nothing), reading each record from LDS at a wave-uniform address (a broadcast)
                 const int lane = lane_now();
-                float4 A = sc.ref_rec[3ull * ubase + (uint32_t)lane];
-                uint32_t um = wave_or(todo);
+                const float4 A = sc.ref_rec[3ull * ubase + (uint32_t)lane];
+                uint32_t um;
                 if (SAME_ORIGIN) {
-                    // every third lane holds (v0, e1.x) of a record: s = o - v0 takes v0's place (three subtractions for the
-                    // chunk's 21 records instead of three per lane and tested entry)
-                    constexpr lanemask V0_LANES = 0x9249249249249249ull;      // lanes 0, 3, 6, ...
-                    A.x = sel(V0_LANES, o.x - A.x, A.x); A.y = sel(V0_LANES, o.y - A.y, A.y); A.z = sel(V0_LANES, o.z - A.z, A.z);
+                    win[lane] = A;
+                    // entries that every direction of the tile rejects are not tested at all (see cull_chunk); what the lanes
+                    // may skip is looked up only for a chunk of which something is left
+                    const uint32_t uleft = (uint32_t)__builtin_amdgcn_readlane((int)(n - c), first);
+                    um = uleft >= COOP_CHUNK ? ((1u << COOP_CHUNK) - 1u) : ((1u << uleft) - 1u);
+                    const uint32_t culled = cull_chunk(win, lane, o);
+#if defined(HVRT_DIAG) && HVRT_DIAG == 28   // entries of cooperative chunks culled | left (before the lanes' skip bits)
+                    if (COUNT && lane == 0) { r.nv += 64 * (uint32_t)__builtin_popcount(um & culled); r.nt += 64 * (uint32_t)__builtin_popcount(um & ~culled); }
+#endif
+                    um &= ~culled;
+                    if (um) um &= wave_or(todo_of(base, mine));
+                } else {
+                    um = wave_or(todo_of(base, mine));
+                    win[lane] = A;
                 }
 #ifdef HVRT_DIAG   // diagnostic build only: what the two counters mean depends on HVRT_DIAG (scripts/diag_counts.py)
-                if (COUNT && lane == 0) {
-                    if (HVRT_DIAG == 11) r.nv += 64;                                    // cooperative chunks
-                    if (HVRT_DIAG == 12) r.nv += 64 * (uint32_t)__builtin_popcount(um);   // cooperative test iterations
-                    if (HVRT_DIAG == 13) r.nv += 64 * (uint32_t)__builtin_popcount(um);
-                }
-                if (COUNT && HVRT_DIAG == 13) r.nt += (uint32_t)__builtin_popcount(todo);   // tests the lanes wanted
+                if (COUNT && lane == 0 && HVRT_DIAG == 11) r.nv += 64;                                    // cooperative chunks
+                if (COUNT && lane == 0 && HVRT_DIAG == 12) r.nv += 64 * (uint32_t)__builtin_popcount(um);   // cooperative test iterations
 #endif
-                win[lane] = A;
-                if (SAME_ORIGIN) {
-                    // entries that every direction of the tile rejects are not tested at all (see cull_chunk)
-#if defined(HVRT_DIAG) && HVRT_DIAG == 28   // wave-level tests culled | left
-                    const uint32_t culled = cull_chunk(win, lane);
-                    if (COUNT && lane == 0) { r.nv += 64 * (uint32_t)__builtin_popcount(um & culled); r.nt += 64 * (uint32_t)__builtin_popcount(um & ~culled); }
-                    um &= ~culled;
-#else
-                    if (um) um &= ~cull_chunk(win, lane);
-#endif
-                }
 #if defined(HVRT_ABLATE) && HVRT_ABLATE == 1      // 1 = lists fetched, no entry tested
                 um = 0;
 #endif
-#if defined(HVRT_DIAG) && HVRT_DIAG == 27   // wave-level tests | of them, those that EVERY direction of the tile rejects by the same side of u (all 64 lanes, with or without a live ray)
-                if (COUNT && SAME_ORIGIN) {
-                    uint32_t um2 = um;
-                    while (um2) {
-                        const int k = __builtin_ctz(um2);
-                        um2 &= um2 - 1u;
-                        const float4* __restrict__ rec = win + 3 * k;
-                        const float4 c0 = rec[0], c1 = rec[1];
-                        const float2 c2 = *reinterpret_cast<const float2*>(rec + 2);
-                        const V3 s_ = { c0.x, c0.y, c0.z }, e1_ = { c0.w, c1.x, c1.y }, e2_ = { c1.z, c1.w, c2.x };
-                        const V3 p_ = cross(d, e2_);
-                        const float det_ = dot(e1_, p_), su_ = dot(s_, p_);
-                        const float ua_ = su_ * __builtin_amdgcn_rcpf(det_);
-                        const bool one_sign = any_lane(!(det_ > EPS)) == 0ull || any_lane(!(det_ < -EPS)) == 0ull;
-                        const bool one_side = any_lane(!(ua_ < -2e-3f)) == 0ull || any_lane(!(ua_ > 1.002f)) == 0ull;
-                        if (lane == 0) { r.nv += 64; if (one_sign && one_side) r.nt += 64; }
-                    }
-                }
-#endif
-                if (work) {
+                if (mine) {
                     while (um) {
                         const int k = __builtin_ctz(um);
                         um &= um - 1u;
@@ -802,16 +792,16 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                         auto keep = [&](float t) { if (!NEAREST || t < r.t) { r.tri = __float_as_uint(c2.y); r.t = t; } };
 #if defined(HVRT_DIAG) && (HVRT_DIAG == 25 || HVRT_DIAG == 26)
                         uint32_t dcs[2] = { 0, 0 };
-                        if (SAME_ORIGIN) { ray_triangle_s({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, d, keep, COUNT ? dcs : nullptr); r.nv += dcs[0]; r.nt += dcs[1]; } else
+                        if (SAME_ORIGIN) { ray_triangle_s(sub(o, { c0.x, c0.y, c0.z }), { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, d, keep, COUNT ? dcs : nullptr); r.nv += dcs[0]; r.nt += dcs[1]; } else
 #endif
-                        if (SAME_ORIGIN) ray_triangle_s({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, d, keep);
-                        else ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, o, d, keep);
+                        ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, c2.x }, o, d, keep);
                     }
                 }
             } else {
 #ifdef HVRT_DIAG
                 if (COUNT && HVRT_DIAG == 11 && lane_now() == 0) r.nt += 64;                  // per-lane (fallback) chunks
 #endif
+                uint32_t todo = todo_of(base, work);
                 while (todo) {
                     const uint32_t k = (uint32_t)__builtin_ctz(todo);
                     todo &= todo - 1;
@@ -826,7 +816,7 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                     });
                 }
             }
-            if (work) c += COOP_CHUNK;
+            if ((SAME_ORIGIN && HVRT_GROUP_SERIAL) ? mine : work) c += COOP_CHUNK;
         }
 #ifndef HVRT_DIAG
         if (COUNT) r.nt += n;
@@ -1032,7 +1022,10 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #ifndef HVRT_COLD_BATCH
 #define HVRT_COLD_BATCH 1
 #endif
-    constexpr long long PULL_CLOCKS = 400000;
+#ifndef HVRT_PULL_CLOCKS
+#define HVRT_PULL_CLOCKS 200000
+#endif
+    constexpr long long PULL_CLOCKS = HVRT_PULL_CLOCKS;
     constexpr uint32_t MAX_BATCH = 8;
     // Eight heads (RenderArgs::n_heads), one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 is the
     // XCD's number): behind the first n_waves slots the queue is cut into chunks of HVRT_QUEUE_CHUNK slots, chunk c belongs to
