@@ -751,7 +751,10 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
             // SAME_ORIGIN: the lanes that stand in the first working lane's voxel are served together; those in other voxels
             // wait for a later round of this loop (HVRT_GROUP_SERIAL)
             const bool mine = work && base == ubase;
-            if ((SAME_ORIGIN && HVRT_GROUP_SERIAL) || any_lane(work && base != ubase) == 0ull) {
+            // (HVRT_GROUP_SERIAL: 1 = always, 2 = when that voxel holds at least half of the working lanes)
+            const unsigned long long gm = any_lane(mine);
+            const bool serve_group = SAME_ORIGIN && (HVRT_GROUP_SERIAL == 1 || (HVRT_GROUP_SERIAL == 2 && 2 * __builtin_popcountll(gm) >= __builtin_popcountll(wm)));
+            if (serve_group || gm == wm) {
                 // every lane with work is in this chunk of this list (same voxel, so same list length): one coalesced
                 // fetch for the wave, parked in the wave's LDS window; every lane then tests the entries that ANY lane
                 // has to test (an entry one lane skips was tested by that ray one voxel ago and missed, so testing it
@@ -816,7 +819,7 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                     });
                 }
             }
-            if ((SAME_ORIGIN && HVRT_GROUP_SERIAL) ? mine : work) c += COOP_CHUNK;
+            if ((serve_group || gm == wm) ? mine : work) c += COOP_CHUNK;
         }
 #ifndef HVRT_DIAG
         if (COUNT) r.nt += n;
