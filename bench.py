@@ -103,25 +103,39 @@ def load_profile(workload):
 
 def render_roofline(prof, k_ms, rays, bytes_per_ray):
     """What binds k_render, as a fraction <= 1 of that resource, plus the HBM yardstick north_star asks for.
-    Everything that is not measured live comes from profiles/traffic.json (which names the counter files)."""
+
+    Live in this run: kernel_ms (HIP events on libhvrt's stream) and everything computed from it alone (requested_GBps;
+    hbm_frac and reuse_factor use the profile's byte count with this run's duration).  Not live: the busy fractions --
+    they come from the counter passes installed under profiles/ (traffic.json names the file per workload) and are
+    labelled so in `from_profiles`.  `frac` is the FLOOR of VALU issue: every vector instruction priced at the guide's
+    2 clocks per wave64 instruction (MI355X_MICROARCH.md; nothing issues faster), so it cannot exceed 1 and cannot
+    overstate; the same count at the 2.2 clocks this repository's micro-benchmark measures for plain VOP1 / VOP2
+    instructions is given beside it.  (Round 2's estimate priced with a static instruction mix exceeded 1 on two
+    workloads and is no longer part of the line.)"""
     requested = bytes_per_ray * rays                       # bytes the REFERENCE algorithm asks for, per launch
     out = {"kernel": "k_render", "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
-           "requested_GBps": requested / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0}
+           "requested_GBps": requested / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
+           "live": ["kernel_ms", "requested_GBps", "algorithmic_bytes_per_ray", "hbm_frac (this run's kernel_ms, the profile's bytes)", "reuse_factor"]}
     traffic = prof.get("k_render_hbm_bytes_per_launch")
     out["traffic"] = traffic
     if traffic:
         out["hbm_frac"] = traffic / (k_ms * 1e-3) / 8e12    # counter-based: HBM is nowhere near binding
         out["reuse_factor"] = requested / traffic           # requested bytes served from cache or never asked for
-    cands = {k: prof[k] for k in ("valu_issue_frac", "vmem_return_frac", "salu_issue_frac", "lds_frac") if k in prof}
+    cands = {k: prof[k] for k in ("valu_issue_frac_guide_clk", "vmem_return_frac", "salu_issue_frac", "lds_frac") if k in prof}
     if cands:
         bound = max(cands, key=cands.get)
-        out.update({"bound": bound.replace("_frac", ""), "achieved": cands[bound], "peak": 1.0,
-                    "unit": "busy clocks of the binding unit per kernel clock", "frac": cands[bound]})
+        name = {"valu_issue_frac_guide_clk": "valu_issue"}.get(bound, bound.replace("_frac", ""))
+        out.update({"bound": name, "achieved": cands[bound], "peak": 1.0,
+                    "unit": "busy clocks of the binding unit per kernel clock", "frac": cands[bound],
+                    "frac_is": "a floor (2 clocks per VALU wave-instruction, the guide's figure); static: from the counter passes under "
+                               "profiles/, not measured in this run"})
         out["candidates"] = cands
-        for k in ("valu_issue_frac_mix", "valu_issue_frac_mix_raw", "valu_insts_per_launch", "valu_clocks_per_inst_floor", "valu_clocks_per_inst",
-                  "vector_loads_per_launch", "vector_loads_per_tile", "kernel_cycles", "l2_hit_rate", "source", "busy_source"):
-            if k in prof:
-                out[k] = prof[k]
+        fp = {k: prof[k] for k in ("valu_issue_frac", "valu_insts_per_launch", "valu_clocks_per_inst_floor", "vector_loads_per_launch",
+                                   "vector_loads_per_tile", "kernel_cycles", "l2_hit_rate", "source", "busy_source") if k in prof}
+        if "valu_issue_frac" in fp:
+            fp["valu_issue_frac_at_2p2_clk"] = fp.pop("valu_issue_frac")
+        fp["source_kind"] = "profiles (static), not this run"
+        out["from_profiles"] = fp
     else:
         # no profile installed for this workload: the HBM yardstick alone (requested bytes against the 8 TB/s peak)
         out.update({"bound": "hbm", "achieved": out["requested_GBps"], "peak": 8000.0, "unit": "GB/s",
@@ -476,6 +490,8 @@ def main():
             out["cold_ms"] = cold_ms                     # first launch of the shape, no tile history
             out["unordered_ms"] = unordered_ms           # HVRT_TILE_ORDER=0: every launch like a first one
             out["unordered_Mrays_s"] = W * H * spp / (unordered_ms * 1e-3) / 1e6 if unordered_ms else None
+            # what holds whatever the previous frame was: no tile history at all (`value` is a replay of one camera)
+            out["value_unconditional"] = out["unordered_Mrays_s"]
             if moving:
                 out["moving_camera"] = moving
         out["roofline_build"] = roof_build

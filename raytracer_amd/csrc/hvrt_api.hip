@@ -781,11 +781,11 @@ int hvrt_build_grid(hvrt_ctx* c, int nx, int ny, int nz, const float mn[3], cons
         if (narrow) {
             if (int r = ensure<uint32_t>(c, c->cnt16, c->cnt16_capacity, npad / 2)) return r;
             HIP_TRY(c, hipMemsetAsync(c->cnt16, 0, npad / 2 * sizeof(uint32_t), s));
-            HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, 4 * sizeof(uint32_t), s));       // offsets[0]
+            HIP_TRY(c, launch_build_reset(c->cnt_base, c->stats, STATS_STATUS + n_chunks, s));       // offsets[0] and the statistics block
         } else {
             HIP_TRY(c, hipMemsetAsync(c->cnt_base, 0, (npad + 8) * sizeof(uint32_t), s));
+            HIP_TRY(c, hipMemsetAsync(c->stats, 0, (STATS_STATUS + n_chunks) * sizeof(uint64_t), s));
         }
-        HIP_TRY(c, hipMemsetAsync(c->stats, 0, (STATS_STATUS + n_chunks) * sizeof(uint64_t), s));
         HIP_TRY(c, launch_count(c->tri_aos, c->n_tris, c->g, narrow ? c->cnt16 : cnt_of(c), narrow, c->stats + STATS_VOL_SUMS, c->ranges, sat ? c->sat_mask : nullptr, s));
         HIP_TRY(c, hipEventRecord(c->ev[1], s));
         HIP_TRY(c, launch_scan(cnt_of(c), narrow ? c->cnt16 : nullptr, c->stats + STATS_VOL_SUMS, n_chunks, status_aux, c->stats, c->occ_bits, s));

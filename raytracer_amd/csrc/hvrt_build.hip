@@ -507,7 +507,11 @@ __global__ __launch_bounds__(SCAN_WAVES * 64) HVRT_SCAN_ATTR void k_scan(uint4* 
         p[k * 64] = o;
     }
 }
-// occupied voxels and longest list: reduction of the per-chunk pairs
+// occupied voxels and longest list: reduction of the per-chunk pairs.  (Round 3 tried to fold this launch into k_scan --
+// the last workgroup to publish its pair adding them all up behind a fence, or every workgroup adding its own pair to the
+// statistics words where there was something to add: 1.48 -> 2.2 / 2.1 ms at 1024^3.  One 16-wave workgroup fits a CU, so
+// whatever wave 0 waits for at the end -- an agent-scope fence, the round trip of one more atomic -- the whole CU waits
+// for, 128 times over.  The launch of its own costs a few microseconds once.)
 // vol_sums (nullable): the count pass's own total, striped (k_count<COUNT16>) -> stats[7]; without it stats[7] is
 // the scan's total, i.e. "nothing to compare against, the counters were wide".  stats[0] != stats[7] at the end:
 // a 16-bit counter carried, nothing built from these offsets may be used.
@@ -611,7 +615,8 @@ __device__ __forceinline__ void bitonic_any_n(Ptr a, uint32_t n, uint32_t tid, u
     }
 }
 
-// TIER 0: SORT_SMALL+1..4096 (static LDS), 1: 4097..32768 (dynamic LDS), 2: above (in global memory)
+// TIER 0: SORT_SMALL+1..4096 (static LDS), 1: 4097..32768 (dynamic LDS) and above (in global memory) -- one launch for
+// the two rare kinds: every launch costs a build its few microseconds, with or without lists to sort
 template <int TIER, int NT>
 __global__ __launch_bounds__(NT) void k_sort_long(const uint32_t* __restrict__ offsets, uint32_t* __restrict__ indices,
                                                   const uint32_t* __restrict__ queue, uint64_t queue_cap,
@@ -625,12 +630,10 @@ __global__ __launch_bounds__(NT) void k_sort_long(const uint32_t* __restrict__ o
         const uint32_t v = queue[q];
         const uint32_t b0 = offsets[v], b1 = offsets[(uint64_t)v + 1];
         const uint32_t len = b1 - b0;
-        const bool mine = TIER == 0 ? (len <= SORT_MID)
-                        : TIER == 1 ? (len > SORT_MID && len <= SORT_BIG)
-                                    : (len > SORT_BIG);
+        const bool mine = TIER == 0 ? (len <= SORT_MID) : (len > SORT_MID);
         if (!mine) continue;   // uniform over the workgroup
         uint32_t* a = indices + b0;
-        if (TIER == 2) {
+        if (TIER == 1 && len > SORT_BIG) {
             bitonic_any_n(a, len, threadIdx.x, NT);
         } else {
             for (uint32_t i = threadIdx.x; i < len; i += NT) lds[i] = a[i];
@@ -1237,6 +1240,18 @@ hipError_t launch_prepare_records(const float* tri_aos, float4* tri_rec, uint32_
     return hipGetLastError();
 }
 
+// the small clears in front of a build with 16-bit counters, in one launch: offsets[0] (with its three pad words) and the
+// statistics block (the counters themselves are cleared by the runtime's fill, the fastest writer there is)
+__global__ __launch_bounds__(256) void k_build_reset(uint4* __restrict__ cnt_base4, uint64_t* __restrict__ stats, uint64_t n_words) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) *cnt_base4 = make_uint4(0u, 0u, 0u, 0u);
+    if (i < n_words) stats[i] = 0ull;
+}
+hipError_t launch_build_reset(uint32_t* cnt_base, uint64_t* stats, uint64_t n_words, hipStream_t s) {
+    k_build_reset<<<(unsigned)((n_words + 255) / 256), 256, 0, s>>>((uint4*)cnt_base, stats, n_words);
+    return hipGetLastError();
+}
+
 hipError_t launch_count(const float* tri_aos, uint32_t T, const GridParams& g, uint32_t* cnt, bool narrow, uint64_t* vol_sums,
                         uint32_t* ranges, uint32_t* sat_mask, hipStream_t s) {
     if (T == 0) return hipSuccess;
@@ -1281,7 +1296,6 @@ hipError_t launch_sort(const uint32_t* offsets, const uint32_t* unsorted, const 
     k_rank_sort<<<(unsigned)((n_launch + 255) / 256), 256, 0, s>>>(unsorted, vox_of, offsets, rc, indices, queue, queue_cap, stats);
     k_sort_long<0, 256><<<2048, 256, 0, s>>>(offsets, indices, queue, queue_cap, stats);
     k_sort_long<1, 1024><<<256, 1024, SORT_BIG * sizeof(uint32_t), s>>>(offsets, indices, queue, queue_cap, stats);
-    k_sort_long<2, 1024><<<256, 1024, 0, s>>>(offsets, indices, queue, queue_cap, stats);
     return hipGetLastError();
 }
 

@@ -108,6 +108,8 @@ constexpr uint64_t STATS_VOL_SUMS = 8, STATS_STATUS = 8 + 1024;
 // narrow: cnt is the 16-bit counter array (two per word; zero on entry) and vol_sums collects the exact total
 // sat_mask (n_tris words, or null): list a triangle only in the voxels of its range that it overlaps (separating-axis test;
 // 32-bit counters only); the verdicts on ranges of up to 32 voxels are left there for launch_fill
+// cnt_base[0..3] <- 0 (16-byte aligned) and stats[0..n_words) <- 0, one launch
+hipError_t launch_build_reset(uint32_t* cnt_base, uint64_t* stats, uint64_t n_words, hipStream_t s);
 hipError_t launch_count(const float* tri_aos, uint32_t n_tris, const GridParams& g, uint32_t* cnt, bool narrow,
                         uint64_t* vol_sums, uint32_t* ranges, uint32_t* sat_mask, hipStream_t s);
 // exclusive scan of n_chunks x SCAN_CHUNK counters; status_aux: 2 x n_chunks u64, the first n_chunks zero on entry.

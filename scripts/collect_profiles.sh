@@ -9,6 +9,7 @@ export TMPDIR=/tmp
 if [ "$step" = pmc ]; then
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render render || exit 1
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_build build || exit 1
+  $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_build_c2 build_c2 || exit 1
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c4 render_c4 || exit 1
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c3 render_c3 || exit 1
   exit 0
@@ -19,6 +20,7 @@ timeout -k 10 300 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err || { tai
 timeout -k 10 300 python bench.py --workload c3 > $O/bench_c3.json 2> $O/bench_c3.err || { tail -5 $O/bench_c3.err; exit 1; }
 timeout -k 10 300 python bench.py --workload c4 > $O/bench_c4.json 2> $O/bench_c4.err || { tail -5 $O/bench_c4.err; exit 1; }
 timeout -k 10 300 python bench.py --workload c5 > $O/bench_c5.json 2> $O/bench_c5.err || { tail -5 $O/bench_c5.err; exit 1; }
+timeout -k 10 300 python bench.py --no-cpu-baseline --moving-camera > $O/bench_c2_moving_camera.json 2> $O/bench_c2_mov.err || { tail -5 $O/bench_c2_mov.err; exit 1; }
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $O/bench_c2_under_rocprof.json 2> $O/kt_bench.err || { tail -5 $O/kt_bench.err; exit 1; }
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_c3 -- python3 $GRAFT_REPO_ROOT/bench.py --workload c3 --no-cpu-baseline > $O/kt_c3.json 2> $O/kt_c3.err || { tail -5 $O/kt_c3.err; exit 1; }

@@ -3,7 +3,7 @@
 # with FETCH_SIZE = 3 and WRITE_SIZE = 2, 4 TCP, 2 TA, 2 TD, 2 GRBM).
 #   scripts/pmc_passes.sh <outdir-name under gpurun_out> render   -> config 2 traversal (scripts/prof_render.py)
 #   scripts/pmc_passes.sh <outdir-name under gpurun_out> render_c3 | render_c4   -> the same kernel on configs 3 and 4 (fewer passes)
-#   scripts/pmc_passes.sh <outdir-name under gpurun_out> build    -> config 5 voxel build (scripts/prof_build.py c5 3)
+#   scripts/pmc_passes.sh <outdir-name under gpurun_out> build | build_c2   -> config 5 / config 2 voxel build (scripts/prof_build.py c5|c2 3)
 set -u
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/$1
@@ -20,6 +20,9 @@ if [ "$what" = render ]; then
 elif [ "$what" = render_c3 ] || [ "$what" = render_c4 ]; then
   prog="scripts/prof_render.py ${what#render_}"
   passes=("FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "GRBM_GUI_ACTIVE")
+elif [ "$what" = build_c2 ]; then
+  prog="scripts/prof_build.py c2 3"
+  passes=("FETCH_SIZE" "WRITE_SIZE" "TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE")
 else
   prog="scripts/prof_build.py c5 3"
   passes=("FETCH_SIZE" "WRITE_SIZE" "TCC_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE")
