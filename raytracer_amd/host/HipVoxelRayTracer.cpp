@@ -169,8 +169,11 @@ bool HipScene::spansDevices(int width, int height) const {
 
 int HipScene::deviceCount() const { return group_ ? hvrt_group_size(group_) : 1; }
 
-void HipScene::setTriangles(const std::vector<Triangle>& tris) {
-    tris_ = tris;
+void HipScene::setTriangles(const std::vector<Triangle>& tris) { setTriangles(std::vector<Triangle>(tris)); }
+
+void HipScene::setTriangles(std::vector<Triangle>&& tris_in) {
+    tris_ = std::move(tris_in);
+    const std::vector<Triangle>& tris = tris_;
     replicated_ = false;
     ck(ctx_, hvrt_set_mesh(ctx_, tris.empty() ? nullptr : &tris[0].v0.x, (uint32_t)tris.size()), "hvrt_set_mesh");
 }
@@ -307,7 +310,7 @@ std::vector<Vec3> HipVoxelRayTracer::render(const Camera& cam, int width, int he
     return frame;
 }
 
-std::vector<std::vector<unsigned char>> HipVoxelRayTracer::renderViewsRgb8(const std::vector<Camera>& cams, int width, int height) {
+std::vector<std::vector<unsigned char>> HipVoxelRayTracer::renderViewsRgb8(const std::vector<Camera>& cams, int width, int height, bool wantHitIds) {
     if (width <= 0 || height <= 0) throw std::runtime_error("render: width and height must be positive");
     if (cams.empty()) return {};
     std::vector<hvrt_camera_frame> fr(cams.size());
@@ -315,14 +318,14 @@ std::vector<std::vector<unsigned char>> HipVoxelRayTracer::renderViewsRgb8(const
         hvrt_make_camera_frame(&cams[i].position.x, &cams[i].lookAt.x, &cams[i].up.x, cams[i].fov, cams[i].aspectRatio, &fr[i]);
     const size_t npx = (size_t)width * height;
     std::vector<unsigned char> all(npx * 3 * cams.size());
-    std::vector<unsigned int> hits(npx * cams.size());
+    std::vector<unsigned int> hits(wantHitIds ? npx * cams.size() : 0);
     uint64_t counters[2] = { 0, 0 };
-    LOG_INFO("[{}] Rendering {} views of {}x{} in one launch...", getMethodName(), cams.size(), width, height);
+    LOG_INFO("[{}] Rendering {} view{} of {}x{} in one launch...", getMethodName(), cams.size(), cams.size() == 1 ? "" : "s", width, height);
     ck(scene_->handle(), hvrt_render_views_rgb8(scene_->handle(), fr.data(), (int)fr.size(), width, height, all.data(),
-                                                hits.data(), counters), "hvrt_render_views_rgb8");
+                                                wantHitIds ? hits.data() : nullptr, counters), "hvrt_render_views_rgb8");
     voxels_ = counters[0];
     tests_ = counters[1];
-    hit_ids_.assign(hits.end() - (std::ptrdiff_t)npx, hits.end());
+    if (wantHitIds) hit_ids_.assign(hits.end() - (std::ptrdiff_t)npx, hits.end()); else hit_ids_.clear();
     const double total = (double)npx * cams.size();
     LOG_INFO("[{}] Rendering complete! kernel {:.3f} ms", getMethodName(), scene_->lastRenderMs());
     LOG_INFO("[{}] Voxels traversed: {}, Avg per ray: {:.1f}", getMethodName(), voxels_, voxels_ / total);

@@ -37,6 +37,7 @@ public:
     // Upload triangles and build the grid ON THE GPU (replaces voxelizeTrianglesDirect,
     // SceneCreator.cpp:197-281).  minBound / maxBound / voxelSize as computeVoxelizationParams gives.
     void setTriangles(const std::vector<cg_datastructures::Triangle>& tris);
+    void setTriangles(std::vector<cg_datastructures::Triangle>&& tris);      // (takes the vector: no second host copy of the mesh)
     void buildGrid(int nx, int ny, int nz, const cg_datastructures::Vec3& mn, const cg_datastructures::Vec3& mx,
                    const cg_datastructures::Vec3& voxelSize);
     // Ingest a CPU-built VoxelGrid (flattens voxels[x][y][z] to the x-fastest CSR).  A grid whose
@@ -85,8 +86,10 @@ public:
     // Several views of the resident scene in ONE launch, quantised to 8-bit RGB on the GPU
     // (ImageSaver.h's conversion): what TraceImageMultiView needs, at 3 bytes per pixel over PCIe.
     // Returns cameras.size() frames of width*height*3 bytes, rows bottom-up like render().
+    // wantHitIds: also fetch the hit-id image of the last view (lastHitIds(); a third more bytes over PCIe)
     std::vector<std::vector<unsigned char>> renderViewsRgb8(const std::vector<cg_datastructures::Camera>& cameras,
-                                                            int width, int height);
+                                                            int width, int height, bool wantHitIds = true);
+    const HipScene& scene() const { return *scene_; }
 
     // false (default): the reference's traversal.  true: nearest-hit mode (hvrt_set_mode(1)), an extension for
     // callers who want a right image rather than the reference's; see include/hvrt.h.

@@ -38,18 +38,28 @@ inline bool saveToPPM(const std::string& filename, const std::vector<Vec3>& pixe
 
 namespace png_detail {
 inline uint32_t crc32(const uint8_t* p, size_t n, uint32_t crc = 0) {
-    static uint32_t table[256];
+    // slicing by 8: eight table look-ups per eight bytes instead of a dependent look-up per byte (a 4K frame is 25 MB)
+    static uint32_t table[8][256];
     static bool init = false;
     if (!init) {
         for (uint32_t i = 0; i < 256; ++i) {
             uint32_t c = i;
             for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
-            table[i] = c;
+            table[0][i] = c;
         }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) table[t][i] = table[0][table[t - 1][i] & 0xFF] ^ (table[t - 1][i] >> 8);
         init = true;
     }
     crc = ~crc;
-    for (size_t i = 0; i < n; ++i) crc = table[(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const uint32_t lo = crc ^ ((uint32_t)p[i] | (uint32_t)p[i + 1] << 8 | (uint32_t)p[i + 2] << 16 | (uint32_t)p[i + 3] << 24);
+        const uint32_t hi = (uint32_t)p[i + 4] | (uint32_t)p[i + 5] << 8 | (uint32_t)p[i + 6] << 16 | (uint32_t)p[i + 7] << 24;
+        crc = table[7][lo & 0xFF] ^ table[6][(lo >> 8) & 0xFF] ^ table[5][(lo >> 16) & 0xFF] ^ table[4][lo >> 24] ^
+              table[3][hi & 0xFF] ^ table[2][(hi >> 8) & 0xFF] ^ table[1][(hi >> 16) & 0xFF] ^ table[0][hi >> 24];
+    }
+    for (; i < n; ++i) crc = table[0][(crc ^ p[i]) & 0xFF] ^ (crc >> 8);
     return ~crc;
 }
 inline void be32(std::vector<uint8_t>& v, uint32_t x) {
@@ -91,7 +101,12 @@ inline bool saveBytesToPNG(const std::string& filename, const uint8_t* q, int wi
         z.push_back(n & 0xFF); z.push_back(n >> 8);
         z.push_back(~n & 0xFF); z.push_back((~n >> 8) & 0xFF);
         z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
-        for (size_t i = 0; i < n; ++i) { a = (a + raw[pos + i]) % 65521; b = (b + a) % 65521; }
+        for (size_t i = 0; i < n;) {       // adler32 with the modulo taken every 5552 bytes (the most that cannot overflow 32 bits)
+            const size_t m = std::min<size_t>(n - i, 5552);
+            for (size_t k = 0; k < m; ++k) { a += raw[pos + i + k]; b += a; }
+            a %= 65521; b %= 65521;
+            i += m;
+        }
         pos += n;
         if (n == 0) break;
     }

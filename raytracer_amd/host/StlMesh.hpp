@@ -21,6 +21,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace hvrt_host {
@@ -115,35 +116,65 @@ private:
         if (corners.size() / 9 != normals_.size() / 3) throw std::runtime_error("ERROR while reading from " + fn + ": facets and vertices do not pair up");
     }
 
+    // One record per corner: sorted as records (16 bytes, coordinates inline) rather than as indices into the corner
+    // array -- the comparisons then read consecutive memory -- and in parallel: chunks sorted by up to 16 threads, merged
+    // pairwise.  A 1.0 M-triangle file (3 M corners) took 315 ms in the weld, most of a 4K TraceImage call, with one
+    // thread sorting indices.
+    struct Corner { float x, y, z; uint32_t i; };
+    static bool corner_less(const Corner& a, const Corner& b) {
+        if (a.x != b.x) return a.x < b.x;
+        if (a.y != b.y) return a.y < b.y;
+        if (a.z != b.z) return a.z < b.z;
+        return a.i < b.i;
+    }
+    static void sort_corners(std::vector<Corner>& v) {
+        const size_t n = v.size();
+        unsigned hw = std::thread::hardware_concurrency();
+        if (const char* e = std::getenv("OMP_NUM_THREADS")) { const int k = std::atoi(e); if (k > 0 && (unsigned)k < hw) hw = (unsigned)k; }
+        unsigned parts = 1;
+        while (parts * 2 <= (hw > 16 ? 16u : hw) && n / (parts * 2) >= 32768) parts *= 2;
+        if (parts == 1) { std::sort(v.begin(), v.end(), corner_less); return; }
+        auto bound = [&](unsigned k) { return n * k / parts; };
+        {
+            std::vector<std::thread> th;
+            for (unsigned k = 0; k < parts; ++k)
+                th.emplace_back([&, k] { std::sort(v.begin() + (std::ptrdiff_t)bound(k), v.begin() + (std::ptrdiff_t)bound(k + 1), corner_less); });
+            for (auto& t : th) t.join();
+        }
+        std::vector<Corner> tmp(n);
+        std::vector<Corner>*src = &v, *dst = &tmp;
+        for (unsigned w = 1; w < parts; w *= 2) {           // runs of w chunks -> runs of 2 w
+            std::vector<std::thread> th;
+            for (unsigned k = 0; k < parts; k += 2 * w)
+                th.emplace_back([&, k, w] {
+                    std::merge(src->begin() + (std::ptrdiff_t)bound(k), src->begin() + (std::ptrdiff_t)bound(k + w),
+                               src->begin() + (std::ptrdiff_t)bound(k + w), src->begin() + (std::ptrdiff_t)bound(k + 2 * w),
+                               dst->begin() + (std::ptrdiff_t)bound(k), corner_less);
+                });
+            for (auto& t : th) t.join();
+            std::swap(src, dst);
+        }
+        if (src != &v) v.swap(tmp);
+    }
+
     void weld(const std::vector<float>& c) {
         const size_t nc = c.size() / 3;
         if (nc == 0) { normals_.clear(); return; }
-        std::vector<uint32_t> order(nc);
-        for (size_t i = 0; i < nc; ++i) order[i] = (uint32_t)i;
-        auto less = [&](uint32_t a, uint32_t b) {
-            const float* p = &c[3 * (size_t)a];
-            const float* q = &c[3 * (size_t)b];
-            if (p[0] != q[0]) return p[0] < q[0];
-            if (p[1] != q[1]) return p[1] < q[1];
-            if (p[2] != q[2]) return p[2] < q[2];
-            return a < b;
-        };
-        std::sort(order.begin(), order.end(), less);
-        auto same = [&](uint32_t a, uint32_t b) {
-            const float* p = &c[3 * (size_t)a];
-            const float* q = &c[3 * (size_t)b];
-            return p[0] == q[0] && p[1] == q[1] && p[2] == q[2];
-        };
+        std::vector<Corner> order(nc);
+        for (size_t i = 0; i < nc; ++i) order[i] = { c[3 * i], c[3 * i + 1], c[3 * i + 2], (uint32_t)i };
+        sort_corners(order);
         std::vector<uint32_t> remap(nc);
         uint32_t cur = 0;
-        coords_.assign(&c[3 * (size_t)order[0]], &c[3 * (size_t)order[0]] + 3);
-        remap[order[0]] = 0;
+        coords_.reserve(nc / 2);
+        coords_.assign({ order[0].x, order[0].y, order[0].z });
+        remap[order[0].i] = 0;
         for (size_t i = 1; i < nc; ++i) {
-            if (!same(order[i], order[i - 1])) {
+            const Corner &a = order[i], &b = order[i - 1];
+            if (!(a.x == b.x && a.y == b.y && a.z == b.z)) {
                 ++cur;
-                coords_.insert(coords_.end(), &c[3 * (size_t)order[i]], &c[3 * (size_t)order[i]] + 3);
+                coords_.push_back(a.x); coords_.push_back(a.y); coords_.push_back(a.z);
             }
-            remap[order[i]] = cur;
+            remap[a.i] = cur;
         }
         const size_t nt = nc / 3;
         std::vector<float> kept_normals;

@@ -53,10 +53,11 @@ VoxelGrid TraceImages::buildSceneOnGpu(const stl_reader::StlMesh<float, unsigned
         std::memcpy(&tris[t].v2, mesh.tri_corner_coords(t, 2), 12);
         std::memcpy(&tris[t].normal, mesh.tri_normal(t), 12);
     }
-    scene.setTriangles(tris);
+    const size_t n_tris = tris.size();
+    scene.setTriangles(std::move(tris));
     // voxelizeTrianglesDirect (SceneCreator.cpp:197-281) -- on the GPU
     scene.buildGrid(nx, ny, nz, mn, mx, Vec3{ vs, vs, vs });
-    LOG_INFO("Voxel grid built on the GPU in {:.3f} ms ({} triangles)", scene.lastBuildMs(), tris.size());
+    LOG_INFO("Voxel grid built on the GPU in {:.3f} ms ({} triangles)", scene.lastBuildMs(), n_tris);
     return VoxelGrid({}, {}, nx, ny, nz, mn, mx, Vec3{ vs, vs, vs }, {});
 }
 
@@ -129,6 +130,19 @@ void TraceImages::renderAndSave(Loaded& l, const Camera& cam, const std::string&
     tracer.setNearestHit(nearestHit);
     tracer.keepHitIds(keepHitIds);
     auto t0 = std::chrono::steady_clock::now();
+    if (!keepPixels && !l.scene->spansDevices(imageWidth, imageHeight)) {
+        // the file holds 8-bit pixels: quantise where the frame is (ImageSaver.h:28-33 on the GPU) and fetch a quarter of the bytes
+        const auto frames = tracer.renderViewsRgb8({ cam }, imageWidth, imageHeight, keepHitIds);
+        lastPixels.clear();
+        lastHitIds = tracer.lastHitIds();
+        const double s = seconds_since(t0);
+        lastPhases.render_ms = 1e3 * s;
+        LOG_INFO("Rendered {} pixels in {:.3f}s ({:.0f} rays/sec)", (size_t)imageWidth * imageHeight, s, (imageWidth * (double)imageHeight) / s);
+        t0 = std::chrono::steady_clock::now();
+        SaveImageBytes(outputDirectory + filename, frames[0].data(), imageWidth, imageHeight);
+        lastPhases.save_ms = 1e3 * seconds_since(t0);
+        return;
+    }
     lastPixels = tracer.render(cam, imageWidth, imageHeight);
     lastHitIds = tracer.lastHitIds();
     const double s = seconds_since(t0);

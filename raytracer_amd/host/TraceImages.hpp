@@ -44,6 +44,10 @@ public:
     std::vector<cg_datastructures::Vec3> lastPixels;
     std::vector<unsigned int> lastHitIds;   // of the last image; single-view renders fetch them only if keepHitIds
     bool keepHitIds = false;
+    // false (default): TraceImage quantises the frame on the GPU (ImageSaver.h's conversion) and fetches 3 bytes per pixel
+    // -- lastPixels stays empty; true: the float frame comes back as IRayTracer::render returns it (12 bytes per pixel) and
+    // is quantised on the host, as in the reference's flow (TraceImages.cpp:215-229).  Same bytes on disk either way.
+    bool keepPixels = false;
     bool lastOk = false;
     // where the last TraceImage / TraceImageMultiView call spent its time, host clock, milliseconds (the reference logs
     // grid generation and rendering, TraceImages.cpp:38-44, 54-67): taking a context (created, or from the process-wide

@@ -75,7 +75,8 @@ int main(int argc, char** argv) {
             ti.imageHeight = H;
             ti.outputDirectory = outdir;
             ti.nearestHit = nearest;
-            ti.keepHitIds = !dump.empty();      // the raw dump holds the hit-id image
+            ti.keepHitIds = !dump.empty();      // the raw dump holds the float frame and the hit-id image
+            ti.keepPixels = !dump.empty();
             std::ofstream pf;
             if (!phases.empty()) pf.open(phases);
             for (int r = 0; r < (repeat < 1 ? 1 : repeat); ++r) {
