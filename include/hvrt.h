@@ -261,7 +261,10 @@ int hvrt_render_part_device(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int w
  *   - at most 2^20 tiles of 8x8 pixels in the rendered part (a 7680x4320 frame has 518 400); larger -> HVRT_ERR_INVALID;
  *   - no tile history is kept or used (every call schedules like a first launch), so it is a few per cent slower
  *     than repeated hvrt_render_part_device calls of one shape, and over-long tiles are not split;
- *   - every call on a GPU, from any context, shares that GPU's array: calls that overlap on one GPU race.
+ *   - every call on a GPU, from any context, shares that GPU's array: calls that overlap on one GPU race;
+ *   - each call records a pair of timing events around its kernel (hvrt_timings.render_ms, hvrt_render_history).  Under
+ *     stream capture those events are captured, not recorded: render_ms then reads -1 and the history entry of such a
+ *     call means nothing -- time a captured graph from outside.
  * Asynchronous on the context's stream. */
 int hvrt_render_part_device_noalloc(hvrt_ctx* ctx, const hvrt_camera_frame* frame, int width, int height,
                                     int spp, uint32_t seed, int tile_rows, int part, int n_parts,

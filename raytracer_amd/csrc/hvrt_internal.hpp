@@ -63,9 +63,21 @@ struct RenderArgs {
     float* t;                // nullable
     unsigned long long* counters;  // 2 x u64, nullable
     unsigned long long* hits;      // 1 x u64, nullable: += pixels whose sample-0 ray hit a triangle (the reference's "Ray hits" log line)
-    uint32_t* tile_counter;  // persistent-thread work queue head (zeroed before launch)
-    // n_heads == 8: the queue has eight heads, tile_counter[16 + h] (zeroed too); head h hands out the slots
-    // n_waves + 8 k + h, so that the slots of one pull lie eight apart (see render_tiles).  1: the single head above.
+    // Queue scratch (the context's is 2048 bytes = 512 words, hvrt_create; the entry point that allocates nothing brings 16 bytes):
+    //   [0]          the single queue head (n_heads == 1)                      zero before a launch
+    //   [1]          number of tiles k_render gave up on (n_abandoned)         zero before a launch
+    //   [8 .. 15]    heads of the segment launches (hvrt_render's half frames: launch b uses word 8 + b as ITS [0])
+    //   [32 .. 40]   seg_slots: slot ranges of those launches (written by k_order_segments)
+    //   [48]         split_started: workgroups of every k_render_split so far that have started -- compared with a running
+    //                total on the host, NEVER reset (hvrt_create zeroes the whole block once)
+    //   [64 + 32 h]  head h of the eight per-XCD heads (n_heads == 8), 128 bytes apart so that their atomics do not queue up
+    //                behind one another in one cache line                          zero before a launch
+    // Who zeroes: render_batch_part's memsets ([0, 16) and [64, 320)) when the queue is not known to be clean, otherwise
+    // the last kernel of the order build behind the previous launch (launch_order_build's clear_heads).
+    uint32_t* tile_counter;
+    // n_heads == 8: the queue has eight heads (above), one per XCD: behind the first n_waves slots (a wave's first slot is its
+    // own number) the queue is cut into chunks of 2^HVRT_QUEUE_CHUNK_LOG2 slots, chunk c belongs to head c & 7, and head h
+    // hands out the slots of its chunks in order (see render_tiles).  1: the single head [0].
     uint32_t n_heads;
     // Work-queue order.  Slot q of the queue is tile order[q] (null: q itself); a tile is 8x8 pixels of one
     // frame, numbered frame-major.  Every launch leaves the duration of each tile (shader clocks / 16) in

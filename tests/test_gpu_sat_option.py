@@ -160,3 +160,23 @@ def test_sat_grid_with_deferred_derived_data(sat_ctx):
         assert np.array_equal(hit, exp[1]) and np.array_equal(t.view(np.uint32), exp[2].view(np.uint32)) and np.array_equal(cnt, exp[3])
     finally:
         sat_ctx.set_deferred_accel(False)
+
+
+def test_hvrt_overlap_in_the_environment_sets_the_default_rule(monkeypatch):
+    """HVRT_OVERLAP=sat: a context starts with the separating-axis rule (what hvrt_set_overlap_test(ctx, 1) selects); any
+    other value leaves the reference's bounding-box rule."""
+    tris = np.ascontiguousarray(meshgen.slivers(200, 3), np.float32)
+    dims = (24, 24, 24)
+    got = {}
+    for value in ("sat", "aabb"):
+        monkeypatch.setenv("HVRT_OVERLAP", value)
+        c = ra.Context(0)
+        try:
+            assert c.counter_width() == (32 if value == "sat" else 16)
+            info, mn, mx, vs = _build(c, tris, dims)
+            got[value] = c.get_csr()
+            want = oracle.voxelize(tris, *dims, mn, vs, sat=(value == "sat"))
+            assert np.array_equal(got[value][0], want[0]) and np.array_equal(got[value][1], want[1])
+        finally:
+            c.close()
+    assert got["sat"][1].size < got["aabb"][1].size

@@ -264,3 +264,11 @@ def test_a_tracer_per_image_reuses_pooled_contexts(tmp_path):
             assert log.count("group created in") == 1 and log.count("group taken from the pool") == 2
             assert log.count("scene replicated to 4 devices") == 3
     assert open(tmp_path / "one.ppm", "rb").read() == open(tmp_path / "four.ppm", "rb").read()
+    # HVRT_CONTEXT_CACHE=0: no pool -- every image creates and destroys its own context; the same file
+    ph = str(tmp_path / "nocache.jsonl")
+    p = subprocess.run([EXE, "render", stl, "nocache.ppm", "--outdir", out, "--size", "640x360", "--grid", "32", "--repeat", "3", "--phases", ph,
+                        "--quiet"], capture_output=True, text=True, timeout=300, env=dict(os.environ, HVRT_CONTEXT_CACHE="0"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    calls = [json.loads(l) for l in open(ph)]
+    assert len(calls) == 3 and all(c["context_ms"] > 1.0 for c in calls), calls          # a context per image costs milliseconds each time
+    assert open(tmp_path / "one.ppm", "rb").read() == open(tmp_path / "nocache.ppm", "rb").read()

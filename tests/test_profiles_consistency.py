@@ -9,6 +9,7 @@ import os
 import pytest
 
 P = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+RND = "r3"          # the round whose files traffic.json and the bench lines were installed from (scripts/install_profiles.py)
 KERNEL = "k_render<false, true, false, false>"
 N_SIMD, N_CU, N_XCD = 1024, 256, 8
 PIXELS = {"c2": 3840 * 2160, "c3": 3840 * 2160, "c4": 7680 * 4320 * 16}
@@ -26,33 +27,44 @@ def _kernel(pmc):
 @pytest.mark.parametrize("w", ["c2", "c3", "c4"])
 def test_traffic_json_follows_from_the_counter_files(w):
     t = _load("traffic.json")[w]
-    k = _kernel(_load(f"r2_pmc_{w}.json"))
+    k = _kernel(_load(f"{RND}_pmc_{w}.json"))
     m = lambda c: k[c]["mean"]
     cyc = m("GRBM_GUI_ACTIVE") / N_XCD
     assert t["kernel_cycles"] == pytest.approx(cyc)
     # gfx950: FETCH_SIZE tallies 128-byte requests at 64 bytes (MI355X_MICROARCH.md), so reads are doubled; KB -> bytes
     assert t["k_render_hbm_bytes_per_launch"] == pytest.approx((2 * m("FETCH_SIZE") + m("WRITE_SIZE")) * 1024)
     assert t["valu_issue_frac"] == pytest.approx(m("SQ_INSTS_VALU") * 2.2 / N_SIMD / cyc, abs=6e-4)
+    # the floor the bench line quotes as `frac`: every vector instruction at the guide's 2 clocks (MI355X_MICROARCH.md)
+    assert t["valu_issue_frac_guide_clk"] == pytest.approx(m("SQ_INSTS_VALU") * 2.0 / N_SIMD / cyc, abs=6e-4)
     assert t["salu_issue_frac"] == pytest.approx(m("SQ_INSTS_SALU") / N_CU / cyc, abs=6e-4)
     assert t["vmem_return_frac"] == pytest.approx(m("SQ_INSTS_VMEM_RD") * 16.3 / N_CU / cyc, abs=6e-4)
-    mix = _load("r2_valu_mix.json")["mean_issue_clocks_per_instruction"]
+    mix = _load(f"{RND}_valu_mix.json")["mean_issue_clocks_per_instruction"]
     assert t["valu_issue_frac_mix_raw"] == pytest.approx(m("SQ_INSTS_VALU") * mix / N_SIMD / cyc, abs=6e-4)
     assert t["valu_issue_frac_mix"] == pytest.approx(min(1.0, t["valu_issue_frac_mix_raw"]), abs=6e-4)
-    for key in ("valu_issue_frac", "valu_issue_frac_mix", "salu_issue_frac", "vmem_return_frac"):
+    for key in ("valu_issue_frac", "valu_issue_frac_guide_clk", "valu_issue_frac_mix", "salu_issue_frac", "vmem_return_frac"):
         assert 0.0 < t[key] <= 1.0, key
 
 
 @pytest.mark.parametrize("w", ["c2", "c3", "c4"])
 def test_bench_line_quotes_traffic_json_and_its_own_clock(w):
     t = _load("traffic.json")[w]
-    d = _load(f"r2_bench_{w}.json")
+    d = _load(f"{RND}_bench_{w}.json")
     r = d["roofline"]
     assert d["config"]["workload"] == w and d["n_gpus"] == 1 and d["unit"] == "Mrays/s" and d["vs_baseline"] is None
     assert d["value"] == pytest.approx(PIXELS[w] / (d["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
     assert r["kernel_ms"] <= d["ms_per_step"]
     cands = r["candidates"]
-    assert r["bound"] + "_frac" == max(cands, key=cands.get) and r["frac"] == cands[r["bound"] + "_frac"] <= 1.0
-    assert r["frac"] == t[r["bound"] + "_frac"] and r["achieved"] / r["peak"] == pytest.approx(r["frac"])
+    key_of = {"valu_issue": "valu_issue_frac_guide_clk"}
+    bound_key = key_of.get(r["bound"], r["bound"] + "_frac")
+    assert bound_key == max(cands, key=cands.get) and r["frac"] == cands[bound_key] <= 1.0
+    assert r["frac"] == t[bound_key] and r["achieved"] / r["peak"] == pytest.approx(r["frac"])
+    # every fraction in the object is <= 1, and what is not measured in the run says where it comes from
+    assert all(v <= 1.0 for v in cands.values()) and r["hbm_frac"] <= 1.0
+    fp = r["from_profiles"]
+    assert fp["source_kind"].startswith("profiles (static)") and fp["source"].startswith("profiles/" + RND + "_pmc_")
+    assert fp["valu_issue_frac_at_2p2_clk"] == t["valu_issue_frac"] <= 1.0
+    assert "valu_issue_frac_mix" not in r and "valu_issue_frac_mix" not in fp         # round 2's estimate exceeded 1 on two workloads
+    assert d["value_unconditional"] == pytest.approx(PIXELS[w] / (d["unordered_ms"] * 1e-3) / 1e6) and d["value_unconditional"] <= d["value"] * 1.02
     assert r["traffic"] == pytest.approx(t["k_render_hbm_bytes_per_launch"])
     assert r["hbm_frac"] == pytest.approx(r["traffic"] / (r["kernel_ms"] * 1e-3) / 8e12)
     requested = r["algorithmic_bytes_per_ray"] * PIXELS[w]
@@ -68,8 +80,8 @@ def test_bench_line_quotes_traffic_json_and_its_own_clock(w):
 def test_kernel_trace_agrees_with_the_events():
     """rocprofv3 --kernel-trace --stats of the same command: the traversal kernel's average is what the line's HIP events
     measured, less the few microseconds of packets the events also bracket (the wait for the split kernel, its join)."""
-    d = _load("r2_bench_c2_under_rocprof.json")
-    with open(os.path.join(P, "r2_bench_c2_kernel_stats.csv")) as f:
+    d = _load(f"{RND}_bench_c2_under_rocprof.json")
+    with open(os.path.join(P, f"{RND}_bench_c2_kernel_stats.csv")) as f:
         rows = [r for r in csv.DictReader(f) if KERNEL in r["Name"]]
     assert len(rows) == 1
     calls, avg_ms = int(rows[0]["Calls"]), float(rows[0]["AverageNs"]) * 1e-6
@@ -80,7 +92,7 @@ def test_kernel_trace_agrees_with_the_events():
 
 def test_build_line_quotes_the_build_counters():
     t = _load("traffic.json")["c5"]
-    d = _load("r2_bench_c5.json")
+    d = _load(f"{RND}_bench_c5.json")
     r = d["roofline"]
     assert d["config"]["workload"] == "c5" and d["unit"] == "ms" and d["higher_is_better"] is False
     assert r["traffic"] == pytest.approx(t["build_hbm_bytes"])
@@ -90,3 +102,12 @@ def test_build_line_quotes_the_build_counters():
     assert r["frac"] == pytest.approx(b_build / (r["csr_ms"] * 1e-3) / 8e12) and r["frac"] <= 1.0
     # the counters say the CSR's kernels move the algorithmic bytes and little more (no wasted re-reads)
     assert 0.9 < r["traffic"] / b_build < 1.1
+
+
+def test_config2_line_carries_its_build_counters():
+    """Round 2's line had roofline_build.traffic = null for config 2 (no counter pass over its build)."""
+    t = _load("traffic.json")["c2"]
+    rb = _load(f"{RND}_bench_c2.json")["roofline_build"]
+    assert rb["traffic"] == pytest.approx(t["build_hbm_bytes"]) and rb["traffic"] > 0
+    assert rb["traffic_source"].startswith("profiles/" + RND + "_pmc_build_c2.json")
+    assert 0.0 < rb["frac"] <= 1.0
