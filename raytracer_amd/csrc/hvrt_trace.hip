@@ -475,6 +475,12 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
 // Arithmetic, voxel sequence, test order and counters are trace_ray's (and so the reference's); only who fetches
 // the bytes differs.  ABORT gives up for the whole wave at once (the clock is a scalar).
 constexpr uint32_t COOP_CHUNK = 21;     // entries per cooperative chunk: 63 lanes x 16 B = 21 records of 48 B
+#ifndef HVRT_SPEC_OFFSETS
+#define HVRT_SPEC_OFFSETS 1      // a consult of the distance field fetches the voxel's list bounds in the same breath
+#endif
+#ifndef HVRT_CULL_DIRECT
+#define HVRT_CULL_DIRECT 0
+#endif
 #ifndef HVRT_GROUP_SERIAL
 #define HVRT_GROUP_SERIAL 0
 #endif
@@ -537,9 +543,12 @@ __device__ __forceinline__ void tile_box(V3 d, float4* __restrict__ box) {
 // Which of the chunk's records (win[3 k .. 3 k + 2] = v0, e1, e2 of record k, k < 21) every direction of the tile rejects:
 // lane k decides for record k (s = o - v0 is the reference's own subtraction, GeometryUtils.cpp:73, done once per record
 // here); returns the mask of culled records.
-__device__ __forceinline__ uint32_t cull_chunk(const float4* __restrict__ win, int lane, V3 o) {
+// (HVRT_CULL_DIRECT: lane k reads its record straight from the record array -- three loads a record apart, all inside the
+// chunk's kilobyte -- instead of the wave fetching the chunk with one coalesced load, parking it in LDS and the lanes
+// reading it back: the common case, nothing of the chunk left, then never touches LDS for the records)
+__device__ __forceinline__ uint32_t cull_chunk(const float4* __restrict__ recs, const float4* __restrict__ win, int lane, V3 o) {
     const int k = lane < (int)COOP_CHUNK ? lane : (int)COOP_CHUNK - 1;
-    const float4* __restrict__ rk = win + 3 * k;
+    const float4* __restrict__ rk = recs + 3 * k;
     const float4 q0 = rk[0], q1 = rk[1];
     const float e2z = reinterpret_cast<const float*>(rk + 2)[0];
     const float4 bc = win[64], bh = win[65];
@@ -639,9 +648,16 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         // phase 1 (as in trace_ray): walk to the next occupied voxel, k empty-space steps at a time
         bool search = alive;
         bool done = false;
+#if HVRT_SPEC_OFFSETS
+        uint32_t sb0 = 0, sb1 = 0;       // the list bounds of the voxel a lane last looked at, fetched WITH its distance byte
+#endif
         for (;;) {
             uint32_t dd = 255u;
+#if HVRT_SPEC_OFFSETS
+            if (search) { dd = dist[f]; const uint32_t* pv = offs + f; sb0 = pv[0]; sb1 = pv[1]; }
+#else
             if (search) dd = dist[f];
+#endif
             search = search && dd != 0u;
             if (any_lane(search) == 0ull) break;
             const uint32_t ds = search ? dd : 255u;
@@ -708,7 +724,11 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         if (any_lane(alive) == 0ull) break;
         uint32_t b0 = 0, b1 = 0;
 #if !defined(HVRT_ABLATE) || HVRT_ABLATE < 2      // ablation builds (timing experiments only): 2 = no lists at all
+#if HVRT_SPEC_OFFSETS
+        if (alive) { b0 = sb0; b1 = sb1; }
+#else
         if (alive) { const uint32_t* pv = offs + f; b0 = pv[0]; b1 = pv[1]; }
+#endif
 #endif
         const bool entered = last != 0u;
         // phase 2: testVoxelTriangles, :267-295 -- every entry is tested, the LAST one that hits wins
@@ -760,23 +780,31 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
                 // has to test (an entry one lane skips was tested by that ray one voxel ago and missed, so testing it
                 // again changes nothing), reading each record from LDS at a wave-uniform address (a broadcast)
                 const int lane = lane_now();
-                const float4 A = sc.ref_rec[3ull * ubase + (uint32_t)lane];
                 uint32_t um;
                 if (SAME_ORIGIN) {
-                    win[lane] = A;
                     // entries that every direction of the tile rejects are not tested at all (see cull_chunk); what the lanes
                     // may skip is looked up only for a chunk of which something is left
                     const uint32_t uleft = (uint32_t)__builtin_amdgcn_readlane((int)(n - c), first);
                     um = uleft >= COOP_CHUNK ? ((1u << COOP_CHUNK) - 1u) : ((1u << uleft) - 1u);
-                    const uint32_t culled = cull_chunk(win, lane, o);
+#if HVRT_CULL_DIRECT
+                    const uint32_t culled = cull_chunk(sc.ref_rec + 3ull * ubase, win, lane, o);
+#else
+                    win[lane] = sc.ref_rec[3ull * ubase + (uint32_t)lane];
+                    const uint32_t culled = cull_chunk(win, win, lane, o);
+#endif
 #if defined(HVRT_DIAG) && HVRT_DIAG == 28   // entries of cooperative chunks culled | left (before the lanes' skip bits)
                     if (COUNT && lane == 0) { r.nv += 64 * (uint32_t)__builtin_popcount(um & culled); r.nt += 64 * (uint32_t)__builtin_popcount(um & ~culled); }
 #endif
                     um &= ~culled;
-                    if (um) um &= wave_or(todo_of(base, mine));
+                    if (um) {
+#if HVRT_CULL_DIRECT
+                        win[lane] = sc.ref_rec[3ull * ubase + (uint32_t)lane];      // something is left to test: the chunk goes to LDS after all
+#endif
+                        um &= wave_or(todo_of(base, mine));
+                    }
                 } else {
                     um = wave_or(todo_of(base, mine));
-                    win[lane] = A;
+                    win[lane] = sc.ref_rec[3ull * ubase + (uint32_t)lane];
                 }
 #ifdef HVRT_DIAG   // diagnostic build only: what the two counters mean depends on HVRT_DIAG (scripts/diag_counts.py)
                 if (COUNT && lane == 0 && HVRT_DIAG == 11) r.nv += 64;                                    // cooperative chunks
