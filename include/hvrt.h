@@ -145,6 +145,20 @@ int hvrt_get_counter_width(const hvrt_ctx* ctx);
  * at most the last 32 launches are kept.  Returns the number written, or -1 (hvrt_last_error says why).
  * No reference counterpart (its render() is synchronous and logs one elapsed time, OctreeLikeRayTracer.cpp:42-118). */
 int hvrt_render_history(hvrt_ctx* ctx, float* ms, int max_entries);
+/* The tile cover of the last launch without counters (hvrt_cover.hip): before such a launch a pass over the triangles
+ * marks the 8x8-pixel tiles of each frame in which some sample's ray can pass the reference's ray / triangle test
+ * (GeometryUtils.cpp:57-97) for some triangle; the pixels of the other tiles receive the reference's result for a miss
+ * without a walk.  dims <- {tiles per row, rows of tiles, words per row}; bits (nullable; rows x words, bit tx & 31 of
+ * word [ty * words + tx / 32], FRAME rows) <- the map of `frame` of that launch.  HVRT_TILE_COVER=0 turns the pass off
+ * (then, and after a launch with counters, HVRT_ERR_INVALID).  Waits for the stream.  No reference counterpart
+ * (OctreeLikeRayTracer.cpp:88-126 walks every ray). */
+int hvrt_get_tile_cover(hvrt_ctx* ctx, int frame, uint32_t* bits, uint64_t capacity_words, uint32_t dims[3]);
+/* The durations the last asynchronous traversal recorded for its 8x8-pixel tiles, in units of 16 shader clocks, tile
+ * t = (frame * rows of tiles + row) * tiles per row + column of the rendered PART (what the next launch of the same shape
+ * orders its work queue by; top bit: the tile is rendered by the 16-wave kernel, the word then holds the sum over its
+ * quads).  A diagnostic: waits for the stream.  Returns the number of tiles, or a negative status.  No reference
+ * counterpart. */
+int hvrt_get_tile_costs(hvrt_ctx* ctx, uint32_t* cost, uint64_t capacity);
 
 /* Callers that only want the voxel grid itself (the CSR that replaces VoxelGrid::voxels, SceneCreator.cpp:197-281)
  * can keep libhvrt's own derived acceleration data -- empty-space distance field, face bits, per-reference records,

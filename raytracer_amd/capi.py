@@ -25,7 +25,7 @@ SYMBOLS = [
     "hvrt_build_grid", "hvrt_set_grid_csr", "hvrt_set_grid_csr_device", "hvrt_get_grid_info", "hvrt_get_csr",
     "hvrt_get_distance_field", "hvrt_get_device_arrays", "hvrt_export_scene_device", "hvrt_make_camera_frame", "hvrt_render", "hvrt_render_part_device", "hvrt_render_batch_part_device", "hvrt_quantise_rgb8_device", "hvrt_render_views_rgb8", "hvrt_trace_device",
     "hvrt_part_rows", "hvrt_assemble_parts_device", "hvrt_trace", "hvrt_render_part_device_noalloc", "hvrt_last_hit_count",
-    "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count", "hvrt_render_history", "hvrt_set_overlap_test",
+    "hvrt_set_deferred_accel", "hvrt_finish_accel", "hvrt_download", "hvrt_device_count", "hvrt_render_history", "hvrt_get_tile_cover", "hvrt_get_tile_costs", "hvrt_set_overlap_test",
     "hvrt_group_create", "hvrt_group_destroy", "hvrt_group_last_error", "hvrt_group_size", "hvrt_group_transport",
     "hvrt_group_member", "hvrt_group_replicate_scene", "hvrt_group_render", "hvrt_group_render_device", "hvrt_group_set_mode",
     "hvrt_group_get_timings", "hvrt_group_last_exchange_bytes", "hvrt_get_mode", "hvrt_clear_scene", "hvrt_download_blocks", "hvrt_get_counter_width",
@@ -119,6 +119,8 @@ def load_library() -> C.CDLL:
     lib.hvrt_last_hit_count.argtypes = [vp, C.POINTER(C.c_uint64)]
     lib.hvrt_download.argtypes = [vp, vp, vp, C.c_uint64]
     lib.hvrt_render_history.argtypes = [vp, C.POINTER(C.c_float), C.c_int]
+    lib.hvrt_get_tile_cover.argtypes = [vp, C.c_int, vp, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.hvrt_get_tile_costs.argtypes = [vp, vp, C.c_uint64]
     lib.hvrt_group_create.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
     lib.hvrt_group_destroy.argtypes = [vp]
     lib.hvrt_group_destroy.restype = None
@@ -405,6 +407,25 @@ class Context:
         if got < 0:
             self._ck(-1)
         return [float(buf[i]) for i in range(got)]
+
+    def tile_cover(self, frame: int = 0) -> np.ndarray:
+        """The tile cover of the last launch without counters: a bool array (rows of tiles, tiles per row), row 0 = the
+        frame's row 0; True where the tile was walked."""
+        dims = (C.c_uint32 * 3)()
+        self._ck(self._lib.hvrt_get_tile_cover(self._h, frame, None, 0, dims))
+        tx, ty, wx = int(dims[0]), int(dims[1]), int(dims[2])
+        words = np.zeros(ty * wx, dtype=np.uint32)
+        self._ck(self._lib.hvrt_get_tile_cover(self._h, frame, words.ctypes.data_as(C.c_void_p), words.size, dims))
+        bits = np.unpackbits(words.view(np.uint8).reshape(ty, wx * 4), axis=1, bitorder="little")
+        return bits[:, :tx].astype(bool)
+
+    def tile_costs(self, n_tiles: int) -> np.ndarray:
+        """Durations (16 shader clocks; top bit: rendered by the 16-wave kernel) of the last launch's tiles (a diagnostic)."""
+        out = np.zeros(n_tiles, dtype=np.uint32)
+        got = self._lib.hvrt_get_tile_costs(self._h, out.ctypes.data_as(C.c_void_p), out.size)
+        if got < 0:
+            self._ck(got)
+        return out[:got]
 
     def set_overlap_test(self, mode: int):
         """0 = every voxel of a triangle's bounding-box range lists it (the reference's rule, default); 1 = those it overlaps

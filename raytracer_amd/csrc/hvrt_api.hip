@@ -70,7 +70,7 @@ struct hvrt_ctx {
     uint32_t* ranges = nullptr;   uint64_t ranges_capacity = 0;
     uint32_t* cnt16 = nullptr;    uint64_t cnt16_capacity = 0;      // 16-bit counters of the count pass, two per word
     bool wait_for_split = true;            // HVRT_SPLIT_WAIT=0: k_render does not wait for k_render_split's workgroups to be resident
-    uint32_t order_split_hint = 0;         // tiles that qualified for k_render_split when the order in use was queued (0: not known)
+    uint32_t order_serial = 0;             // number of the order build that made the order in use (it leaves it beside its split count, split_hint[1])
     uint32_t split_started_total = 0;      // workgroups of all k_render_split launches that report in (wraps; compared as a difference)
     bool narrow_counters = true;   // HVRT_BUILD_NARROW=0; cleared for good once a list of this context outgrew 16 bits
     uint32_t* occ_bits = nullptr; uint64_t occ_bits_capacity = 0;   // one bit per voxel, left by the scan for the distance field
@@ -112,10 +112,25 @@ struct hvrt_ctx {
     uint32_t* split_hint = nullptr;
     uint64_t* stats_host = nullptr;        // pinned landing place of a build's eight statistics words (a copy into pageable memory waits inside hipMemcpyAsync)
     uint32_t* split_hint_dev = nullptr;    // the same word as the device addresses it
-    unsigned long long* cost_sum = nullptr;   // 2 x u64: this launch's and the previous launch's sum of tile costs
+    unsigned long long* cost_sum = nullptr;   // 4 x u64: this launch's and the previous launch's sum of tile costs [0, 1] and walked-tile counts [2, 3]
     int cost_parity = 0;
     bool adaptive_order = true;    // HVRT_TILE_ORDER=0 keeps the natural order
     bool adaptive_split = true;    // HVRT_TILE_SPLIT=0 leaves every tile to k_render
+    // tile cover (hvrt_cover.hip): a pre-pass over the triangles in front of every launch without counters marks the tiles in
+    // which a ray can hit something; k_render does not walk the others.  HVRT_TILE_COVER=0 walks every tile.
+    bool tile_cover = true;
+    uint32_t cover_budget = 1024;   // HVRT_TILE_COVER_BUDGET: block tests per triangle before blocks are marked whole
+    uint32_t* cover_bits = nullptr; uint64_t cover_capacity = 0;
+    CoverArgs cover_last = {};     // the last launch that ran the pre-pass (n_frames == 0: none since the scene changed)
+    // ... and its cameras: a launch with the same cameras, frame size and mesh finds its cover standing (HVRT_TILE_COVER_CACHE=0:
+    // every launch runs the pre-pass)
+    hvrt_camera_frame cover_frames[HVRT_MAX_BATCH_FRAMES] = {};
+    bool cover_cache = true;
+    // supersampled launches render their over-long tiles sample by sample inside k_render (RenderArgs::sample_rgb) instead of
+    // handing them to k_render_split; HVRT_SAMPLE_SPLIT=0: the split kernel for every launch
+    bool sample_split = true;
+    float4* sample_rgb = nullptr; uint64_t sample_rgb_capacity = 0;
+    uint32_t* sample_done = nullptr; uint64_t sample_done_capacity = 0;
     bool cost_valid = false;
     int cost_key[8] = {};
     hvrt_camera_frame cost_cam = {};   // the (first) camera of the launch the tile durations come from
@@ -469,7 +484,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipEventCreateWithFlags(&c->ev_split_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void**)&c->split_hint, 128, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-    *c->split_hint = 1u;
+    c->split_hint[0] = 1u; c->split_hint[1] = 0u;
     c->stats_host = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(c->split_hint) + 64);      // 8 words of the same pinned block
     if ((e = hipHostGetDevicePointer((void**)&c->split_hint_dev, c->split_hint, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     for (auto& ev : c->ev)
@@ -493,6 +508,10 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if (const char* v = getenv("HVRT_OVERLAP")) c->overlap_mode = strcmp(v, "sat") == 0 ? 1 : 0;      // the default of hvrt_set_overlap_test
     if (const char* v = getenv("HVRT_TILE_ORDER")) c->adaptive_order = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_SPLIT")) c->adaptive_split = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_TILE_COVER")) c->tile_cover = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_TILE_COVER_CACHE")) c->cover_cache = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_SAMPLE_SPLIT")) c->sample_split = atoi(v) != 0;
+    if (const char* v = getenv("HVRT_TILE_COVER_BUDGET")) { const int b = atoi(v); if (b >= 1) c->cover_budget = (uint32_t)b; }
     if (const char* v = getenv("HVRT_HISTORY_MAX_DEG")) c->history_max_rad = (float)atof(v) * 3.14159265f / 180.0f;
     if (const char* v = getenv("HVRT_TILE_ABORT_US")) {
         const long long us = atoll(v);
@@ -557,7 +576,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->df_stream) (void)hipStreamSynchronize(c->df_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->sat_mask, c->cnt16, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
-                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned,
+                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned, c->cover_bits, c->sample_rgb, c->sample_done,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
     c->ev[6] = c->ev[7] = nullptr;          // aliases of ring entries
@@ -640,6 +659,7 @@ int hvrt_clear_scene(hvrt_ctx* c) {
     c->n_refs = c->n_occupied = 0;
     c->max_list = 0;
     c->cost_valid = false;
+    c->cover_last.n_frames = 0;
     c->order_ahead = false;
     c->mode = 0;
     c->defer_accel = false;
@@ -682,6 +702,7 @@ static int adopt_mesh(hvrt_ctx* c, const void* src, uint32_t n_tris, hipMemcpyKi
     c->n_tris = n_tris;
     c->has_grid = false;
     c->cost_valid = false;
+    c->cover_last.n_frames = 0;
     (void)join_distance_field(c, c->stream);   // left over from a build that failed half-way
     if (n_tris) {
         HIP_TRY(c, hipMemcpyAsync(c->tri_aos, src, (size_t)n_tris * 48, kind, c->stream));
@@ -1139,7 +1160,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     if (int r = ensure<uint32_t>(c, c->tile_order, c->tile_order_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->split_tiles, c->split_tiles_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->abandoned, c->abandoned_capacity, n_tiles)) return r;
-    if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, 2 * (order_blocks + 1))) return r;
+    if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, 3 * (order_blocks + 1))) return r;
     // ... and of a view near this one: a queue ordered by the durations of a view a few degrees away is worse than an
     // unordered one (config 2, an orbit in steps of 2 / 3 / 5 / 7 degrees: 1.55 / 1.71 / 1.89 / 2.09 ms per frame with the
     // previous frame's durations, 1.69-1.75 with none; scripts/time_moving.py), so past 2.5 degrees this is a first launch
@@ -1162,25 +1183,72 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     ra.order = reuse ? c->tile_order : nullptr;
     ra.split_tiles = c->split_tiles;
     ra.n_split = c->order_blocks + order_blocks;
+    ra.n_front = c->tile_counter + 49;
     ra.split_started = nullptr;
     ra.abandoned = c->abandoned;
     ra.n_abandoned = c->tile_counter + 1;
     ra.abort_ticks = c->abort_ticks;
     ra.tile_cost = c->tile_cost;
     ra.cost_sum = c->cost_sum + c->cost_parity;
+    ra.walked = ra.cost_sum + 2;
     ra.seg_slots = nullptr; ra.seg = 0;
+    ra.cover = nullptr; ra.cover_words_x = 0; ra.cover_frame_words = 0;
+    ra.sample_rgb = nullptr; ra.sample_done = nullptr; ra.sample_cap = 0;
+    { const char* v = getenv("HVRT_DEBUG_TILE_START"); ra.debug_start = v && atoi(v) != 0; }
+    CoverArgs ca;
+    const bool use_cover = c->tile_cover && !d_counters && n_tiles != 0 && scene_of(c).n_tris != 0 &&
+                           cover_geometry(width, height, n_frames, scene_of(c).n_tris, ca) == 0;
+    bool cover_stands = false;
+    if (use_cover) {
+        const uint32_t* const before = c->cover_bits;
+        if (int r = ensure<uint32_t>(c, c->cover_bits, c->cover_capacity, cover_words(ca))) return r;
+        const CoverArgs& l = c->cover_last;
+        cover_stands = c->cover_cache && before == c->cover_bits && l.n_frames == n_frames && l.width == width && l.height == height &&
+                       memcmp(c->cover_frames, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames) == 0;
+    }
     next_render_events(c);
     HIP_TRY(c, hipEventRecord(c->ev[6], s));
+    if (use_cover) {
+        // (inside the timed region: render_ms is the pre-pass and the traversal)
+        ca.frames = ds; ca.frame0 = frames[0];
+        cover_bind(ca, c->cover_bits); ca.budget = c->cover_budget;
+        if (!cover_stands) {
+            HIP_TRY(c, hipMemsetAsync(ca.bits, 0, cover_zero_words(ca) * sizeof(uint32_t), s));
+            HIP_TRY(c, launch_cover(scene_of(c), ca, s));
+            memcpy(c->cover_frames, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames);
+        }
+        ra.cover = ca.bits; ra.cover_words_x = ca.words_x; ra.cover_frame_words = ca.frame_words;
+        c->cover_last = ca;
+    } else {
+        c->cover_last.n_frames = 0;
+    }
     const bool queued_behind_ev6 = !c->queue_clean;
     if (!c->queue_clean) {
         HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // [0] a single head, [1] abandoned count, [8..15] the heads of segment launches
         HIP_TRY(c, hipMemsetAsync(c->tile_counter + 64, 0, 8 * 32 * sizeof(uint32_t), s));   // the queue's eight heads, 128 bytes apart
         HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(ra.walked, 0, sizeof(unsigned long long), s));
     }
     c->queue_clean = false;
     if (reuse && n_tiles) {
         const bool may_split = c->order_may_split;
-        if (may_split) {
+        // supersampled: the over-long tiles stay in k_render, one item per sample (not for a frame in several launches,
+        // whose launches share the words behind the queue head)
+        bool by_sample = may_split && c->sample_split && spp >= 2 && !d_counters && !(plan && plan->n > 1 && n_frames == 1);
+        if (by_sample) {
+            uint64_t cap = (64ull << 20) / ((uint64_t)spp * 64u * sizeof(float4));
+            cap = cap > 4096u ? 4096u : cap;
+            if (cap == 0) {
+                by_sample = false;
+            } else {
+                const uint32_t* const before = c->sample_done;
+                if (int r = ensure<float4>(c, c->sample_rgb, c->sample_rgb_capacity, cap * (uint64_t)spp * 64u)) return r;
+                if (int r = ensure<uint32_t>(c, c->sample_done, c->sample_done_capacity, 4096u)) return r;
+                if (before != c->sample_done) HIP_TRY(c, hipMemsetAsync(c->sample_done, 0, 4096u * sizeof(uint32_t), s));
+                ra.sample_rgb = c->sample_rgb; ra.sample_done = c->sample_done; ra.sample_cap = (uint32_t)cap;
+            }
+        }
+        if (may_split && !by_sample) {
             // the tiles too long for one wave go first and beside the others, on the second stream
             // (the fork is the launch's own first timing event when nothing was queued behind it: one packet fewer in the stream)
             hipEvent_t fork = c->ev[6];
@@ -1189,7 +1257,12 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             RenderArgs rsplit = ra;
             rsplit.split_started = c->wait_for_split ? c->tile_counter + 48 : nullptr;      // a word of the 64-word scratch, never reset
             uint32_t nb = 0;
-            HIP_TRY(c, launch_render_split(scene_of(c), rsplit, c->n_cus, c->aux_stream, &nb, c->order_split_hint));
+            // how many tiles that order build found for the split kernel sizes it -- if the build has run by now and left its
+            // number; otherwise the count is not known and the kernel is sized for any (a stale small count once gave 563
+            // tiles 16 workgroups: 11 ms for a 0.6 ms launch)
+            const uint32_t serial_seen = __atomic_load_n(c->split_hint + 1, __ATOMIC_ACQUIRE);
+            const uint32_t expected = serial_seen == c->order_serial ? __atomic_load_n(c->split_hint, __ATOMIC_RELAXED) : 0u;
+            HIP_TRY(c, launch_render_split(scene_of(c), rsplit, c->n_cus, c->aux_stream, &nb, expected));
             HIP_TRY(c, hipEventRecord(c->ev_split_join, c->aux_stream));
             if (rsplit.split_started && nb) {
                 // k_render's persistent waves would otherwise take every slot before the split kernel is on (see k_wait_split_started)
@@ -1209,13 +1282,13 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
                 rs.tile_counter = c->tile_counter + 8 + b;
                 rs.n_heads = 1;
                 HIP_TRY(c, launch_render(scene_of(c), rs, c->n_cus, false, s));
-                if (b == 0 && may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
+                if (b == 0 && may_split && !by_sample) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
                 HIP_TRY(c, hipEventRecord(c->ev_seg[b], s));
             }
             plan->used = true;
         } else {
             HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, false, s));
-            if (may_split) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
+            if (may_split && !by_sample) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_split_join, 0));
         }
     } else {
         // no history: the kernel may give up on over-long tiles; k_render_split renders those behind it (none,
@@ -1233,21 +1306,21 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     HIP_TRY(c, hipEventRecord(c->ev[7], s));       // render_ms: the traversal (k_render, and k_render_split beside or behind it)
     // behind the traversal: the order for the next launch of this shape from the durations this one records, and the
     // clean queue head / cost sum that launch starts from
-    if (c->adaptive_order && n_tiles) {
+    if (c->adaptive_order && n_tiles && !ra.debug_start) {      // (the diagnostic's start times are no durations: no order from them)
         const bool may_split = c->adaptive_split && *(volatile uint32_t*)c->split_hint != 0u;
         // (its last kernel also clears the queue heads and the next launch's cost sum: two memsets fewer in the stream)
         HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, ra.cost_sum, c->n_cus, may_split, c->order_blocks,
-                                      c->tile_order, c->split_tiles, c->split_hint_dev, c->tile_counter,
+                                      c->tile_order, c->split_tiles, c->split_hint_dev, ++c->order_serial, c->tile_counter,
                                       c->cost_sum + (c->cost_parity ^ 1), s));
         c->order_ahead = true;
         c->order_may_split = may_split;
-        c->order_split_hint = *(volatile uint32_t*)c->split_hint;      // as of the last order build that has run: sizes the next k_render_split
         c->cost_parity ^= 1;
     } else {
         c->cost_parity ^= 1;
         HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->tile_counter + 64, 0, 8 * 32 * sizeof(uint32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity, 0, sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity + 2, 0, sizeof(unsigned long long), s));
     }
     c->queue_clean = true;
     memcpy(c->cost_key, key, sizeof key);
@@ -1300,6 +1373,42 @@ int hvrt_download_blocks(hvrt_ctx* c, void* dst, const void* d_src, uint64_t byt
         return fail(c, HVRT_ERR_INVALID, "download_blocks: blocks of %llu bytes %llu bytes apart overlap", (unsigned long long)block_bytes, (unsigned long long)dst_stride);
     if (int r = download(c, dst, d_src, bytes, c->stream, block_bytes, dst_stride)) return r;
     return hvrt_synchronize(c);
+}
+
+int hvrt_get_tile_cover(hvrt_ctx* c, int frame, uint32_t* bits, uint64_t capacity_words, uint32_t dims[3]) {
+    if (!c || !dims) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    const CoverArgs& ca = c->cover_last;
+    if (ca.n_frames < 1) return fail(c, HVRT_ERR_INVALID, "tile cover: the last launch ran without the pre-pass (counters, HVRT_TILE_COVER=0) or there was none");
+    if (frame < 0 || frame >= ca.n_frames) return fail(c, HVRT_ERR_INVALID, "tile cover: frame %d outside 0..%d", frame, ca.n_frames - 1);
+    dims[0] = ca.tiles_x; dims[1] = ca.tiles_y; dims[2] = ca.words_x;
+    const uint64_t n = (uint64_t)ca.tiles_y * ca.words_x;
+    if (!bits) return HVRT_OK;
+    if (capacity_words < n) return fail(c, HVRT_ERR_INVALID, "tile cover: %llu words needed, %llu given", (unsigned long long)n, (unsigned long long)capacity_words);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(bits, ca.bits + (uint64_t)frame * ca.frame_words, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HVRT_OK;
+}
+
+int hvrt_debug_tile_slots(hvrt_ctx* c, uint32_t* slots, uint64_t capacity) {      // not in hvrt.h: scripts/tile_starts.py
+    if (!c || !slots || !c->cost_valid) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    const uint64_t n = render_tile_count(c->cost_key[0], hvrt_part_rows(c->cost_key[1], c->cost_key[2], c->cost_key[3], c->cost_key[4]), c->cost_key[5]);
+    if (capacity < n) return HVRT_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(slots, c->abandoned, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return HVRT_OK;
+}
+
+int hvrt_get_tile_costs(hvrt_ctx* c, uint32_t* cost, uint64_t capacity) {
+    if (!c || !cost) return HVRT_ERR_INVALID;
+    if (int r = bind(c)) return r;
+    if (!c->cost_valid) return fail(c, HVRT_ERR_INVALID, "tile costs: no launch yet");
+    const uint64_t n = render_tile_count(c->cost_key[0], hvrt_part_rows(c->cost_key[1], c->cost_key[2], c->cost_key[3], c->cost_key[4]), c->cost_key[5]);
+    if (capacity < n) return fail(c, HVRT_ERR_INVALID, "tile costs: %llu words needed, %llu given", (unsigned long long)n, (unsigned long long)capacity);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(cost, c->tile_cost, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return (int)(n > 0x7FFFFFFFull ? 0x7FFFFFFF : n);
 }
 
 int hvrt_render_history(hvrt_ctx* c, float* ms, int max_entries) {

@@ -66,8 +66,10 @@ struct RenderArgs {
     // Queue scratch (the context's is 2048 bytes = 512 words, hvrt_create; the entry point that allocates nothing brings 16 bytes):
     //   [0]          the single queue head (n_heads == 1)                      zero before a launch
     //   [1]          number of tiles k_render gave up on (n_abandoned)         zero before a launch
+    //   [2]          head of the sample-item queue (sample_rgb)                 zero before a launch
     //   [8 .. 15]    heads of the segment launches (hvrt_render's half frames: launch b uses word 8 + b as ITS [0])
     //   [32 .. 40]   seg_slots: slot ranges of those launches (written by k_order_segments)
+    //   [49]         n_front of the order in use (written by the order build, never reset)
     //   [48]         split_started: workgroups of every k_render_split so far that have started -- compared with a running
     //                total on the host, NEVER reset (hvrt_create zeroes the whole block once)
     //   [64 + 32 h]  head h of the eight per-XCD heads (n_heads == 8), 128 bytes apart so that their atomics do not queue up
@@ -88,6 +90,7 @@ struct RenderArgs {
     // k_render_split, 16 waves per tile (split_tiles[0, *n_split), both written by k_order_place; with order).
     const uint32_t* split_tiles;
     const uint32_t* n_split;
+    const uint32_t* n_front;      // (nullable; with order) how many slots at the queue's head hold tiles put there for their length: pulled one at a time
     uint32_t* split_started;      // (nullable) k_render_split: every workgroup adds 1 when it starts (launch_wait_split_started)
     // k_render gives up on a tile whose rays are still inside long lists abort_ticks after they set out and
     // appends it to abandoned[*n_abandoned++] (zeroed before the launch); a k_render_split launch behind it
@@ -97,11 +100,25 @@ struct RenderArgs {
     long long abort_ticks;   // in ticks of the constant 100 MHz clock (wall_clock64), per sample of a pixel
     uint32_t* tile_cost;
     unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
+    unsigned long long* walked;     // (nullable) += the tiles this launch walked (zeroed before it; the order build reads it at cost_sum[2])
     // A frame rendered as several launches over consecutive ranges of ONE ordered queue (the host-facing hvrt_render:
     // the rows a launch completes travel over PCIe while the next launch traces): this launch takes the slots
     // [seg_slots[seg], seg_slots[seg + 1]) and its queue head starts at 0.  Null: the whole queue.
     const uint32_t* seg_slots;
     int seg;
+    // Supersampled launches (spp > 1) render the tiles of split_tiles sample by sample inside k_render instead of handing them
+    // to k_render_split (null: they do not): sample_rgb holds sample_cap x spp x 64 colours, sample_done one counter per
+    // tile of the list (zero before the launch; the kernel leaves them zero), and word [2] of the queue scratch is the head
+    // of the item queue (zero before the launch).
+    float4* sample_rgb;
+    uint32_t* sample_done;
+    uint32_t sample_cap;
+    // Tile cover (hvrt_cover.hip; null: every tile is walked): bit tx & 31 of cover[frame * cover_frame_words + (y / 8) *
+    // cover_words_x + tx / 32] is clear when no sample of the 8x8 tile at column tile tx and FRAME row y can hit anything --
+    // its pixels get the miss result without a walk.  Only the kernels without counters look at it.
+    const uint32_t* cover;
+    uint32_t cover_words_x, cover_frame_words;
+    int debug_start;         // a diagnostic (HVRT_DEBUG_TILE_START=1 at the time of the call): tile_cost <- when each tile started (10-ns ticks, low 32 bits) instead of how long it took
 };
 
 // ---- launchers (hvrt_build.hip) ----
@@ -177,12 +194,13 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
 // before k_render's persistent waves take every slot there is.
 hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_t timeout_us, hipStream_t s);
 // split_tiles <- the tiles for k_render_split; order <- the others: long tiles (cost > 2.5 x mean) first, the
-// rest behind them in natural order.  block_count: 2 x (ceil(n_tiles / 256) + 1) u32 of scratch; afterwards
+// rest behind them in natural order.  block_count: 3 x (ceil(n_tiles / 256) + 1) u32 of scratch; afterwards
 // block_count[ceil(n_tiles / 256)] is the number of split tiles (0 when may_split is false).  *wants_split
 // (device-visible host memory) <- the number of tiles that qualify for splitting, whatever may_split says.
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
-                              uint32_t* wants_split, uint32_t* clear_heads /* 24 words, nullable */,
+                              uint32_t* wants_split /* 2 words: the count, then `serial` */, uint32_t serial,
+                              uint32_t* clear_heads /* 24 words, nullable */,
                               unsigned long long* clear_sum /* nullable */, hipStream_t s);
 // seg_slots[0..n_seg] <- the slot ranges of n_seg launches over the queue launch_order_build left: launch b covers the
 // tiles of tile rows [row_bounds[b], row_bounds[b + 1]) that are in k_render's queue behind the long ones; launch 0
@@ -194,5 +212,31 @@ hipError_t launch_trace(const SceneDev& sc, const float* origins, const float* d
 hipError_t launch_quantise_rgb8(const float* rgb /* 16-B aligned */, uint64_t n_values, uint8_t* out /* 4-B aligned */, hipStream_t s);
 hipError_t launch_assemble(const void* parts, int width, int height, int tile_rows, int n_parts,
                            int slab_rows, int bytes_per_pixel, void* frame, hipStream_t s);
+
+// ---- launchers (hvrt_cover.hip) ----
+struct CoverArgs {
+    const hvrt_camera_frame* frames;   // n_frames frames in DEVICE memory, or null: frame0
+    hvrt_camera_frame frame0;
+    int n_frames;
+    int width, height;                 // the full frame
+    uint32_t tiles_x, tiles_y;         // 8x8-pixel tiles of the full frame
+    uint32_t words_x;                  // words per row of tiles, at every level
+    int levels;                        // L: the root block is 2^L x 2^L tiles
+    uint32_t frame_words;              // (L + 1) x tiles_y x words_x: one frame's pyramid; level 0 comes first and is the result
+    uint32_t* bits;                    // n_frames x frame_words words, ZERO on entry
+    uint32_t* slow_count;              // n_frames words, ZERO on entry: triangles queued for the general case, per frame
+    uint32_t* slow_queue;              // n_frames x slow_cap triangle indices
+    uint32_t slow_cap;
+    uint32_t budget;                   // block tests per triangle before it marks blocks whole
+};
+// fills in the geometry fields (everything but frames / frame0 / the pointers / budget); nonzero: the frame is too large for a pyramid
+int cover_geometry(int width, int height, int n_frames, uint32_t n_tris, CoverArgs& ca);
+// one allocation of cover_words(ca) words holds everything: cover_bind points bits / slow_count / slow_queue into it; its
+// first cover_zero_words(ca) words must be zero before launch_cover
+uint64_t cover_words(const CoverArgs& ca);
+uint64_t cover_zero_words(const CoverArgs& ca);
+void cover_bind(CoverArgs& ca, uint32_t* words);
+// marks, in level 0 of ca.bits, every tile of every frame in which some sample's ray may hit some triangle of sc
+hipError_t launch_cover(const SceneDev& sc, const CoverArgs& ca, hipStream_t s);
 
 }  // namespace hvrt

@@ -9,6 +9,7 @@
 #include "hvrt_internal.hpp"
 
 #include <stddef.h>
+#include <stdlib.h>
 
 #include <float.h>
 #include <limits.h>
@@ -932,7 +933,8 @@ struct PixelResult {
 template <bool COUNT, bool INLINE, bool NEAREST, int RAYS, bool ABORT>
 __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArgs& ra, const hvrt_camera_frame* __restrict__ cf,
                                              uint32_t tx, uint32_t ty, int lane, int px_x, int px_y, bool alive,
-                                             float4* __restrict__ win, long long wall0, PixelResult& out) {
+                                             float4* __restrict__ win, long long wall0, PixelResult& out, int only = -1) {
+    // only >= 0: that sample alone, its colour as it is (out.hit / out.t are sample 0's or a miss)
     // The frame is wave-uniform and nothing writes it while the kernel runs, but the compiler cannot see the second
     // part (the tile loop stores pixels) and would fetch it with vector loads into twelve vector registers that stay
     // live across the walk -- four of them in scratch at 64 registers.  Read through the constant address space it
@@ -957,7 +959,7 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
     asm volatile("" : "+v"(org.x), "+v"(org.y), "+v"(org.z));
     V3 acc = { 0.0f, 0.0f, 0.0f };
     out.hit = HVRT_MISS; out.t = FLT_MAX; out.nv = 0; out.nt = 0;
-    for (int s = 0; s < ra.spp; ++s) {
+    for (int s = only < 0 ? 0 : only; s < (only < 0 ? ra.spp : only + 1); ++s) {
         // RAYS == 64 (k_render): the pixel's coordinates are worked out again per sample (see pixel_coords);
         // k_render_split's lanes share pixels and pass theirs in
         int x = px_x, y = px_y, lr_unused = 0;
@@ -979,13 +981,30 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
         else r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, wall0 + ra.abort_ticks * (s + 1));
         if (ABORT && r.tri == HVRT_ABORTED) return false;
         const V3 c = shade(sc, r, org, v);
-        if (ra.spp == 1) acc = c; else acc = add(acc, c);
+        if (ra.spp == 1 || only >= 0) acc = c; else acc = add(acc, c);
         if (s == 0) { out.hit = r.tri; out.t = r.t; }
         if (COUNT) { out.nv += r.nv; out.nt += r.nt; }
     }
-    if (ra.spp > 1) { const float n = ra.spp_f; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+    if (ra.spp > 1 && only < 0) { const float n = ra.spp_f; acc = { acc.x / n, acc.y / n, acc.z / n }; }
     out.rgb = acc;
     return true;
+}
+// render_pixel for a pixel none of whose samples can hit anything (RenderArgs::cover): what it leaves for samples that all
+// miss -- the background of every sample's own v, accumulated and averaged in the same order -- without rays or walks
+__device__ __forceinline__ void background_pixel(const RenderArgs& ra, uint32_t tx, uint32_t ty, PixelResult& out) {
+    V3 acc = { 0.0f, 0.0f, 0.0f };
+    out.hit = HVRT_MISS; out.t = FLT_MAX; out.nv = 0; out.nt = 0;
+    for (int s = 0; s < ra.spp; ++s) {
+        int x, lr_unused, y;
+        pixel_coords(ra, tx, ty, -1, x, lr_unused, y);
+        float jx = 0.0f, jy = 0.0f;
+        if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
+        const float v = ((float)y + jy) / ra.height_f;
+        const V3 c = { 0.5f + 0.3f * v, 0.5f + 0.3f * v, 0.7f + 0.3f * v };      // shade() on a miss
+        if (ra.spp == 1) acc = c; else acc = add(acc, c);
+    }
+    if (ra.spp > 1) { const float n = ra.spp_f; acc = { acc.x / n, acc.y / n, acc.z / n }; }
+    out.rgb = acc;
 }
 __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame, int local_row, int x, const PixelResult& px) {
     const size_t p = ((size_t)frame * ra.slab_rows + local_row) * ra.width + x;
@@ -1022,6 +1041,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     // range of the queue's slots only (RenderArgs::seg_slots)
     const uint32_t slot0 = ra.seg_slots ? ra.seg_slots[ra.seg] : 0u;
     const uint32_t n_queue = ra.seg_slots ? ra.seg_slots[ra.seg + 1] : (ra.order ? n_tiles - *ra.n_split : n_tiles);
+    const uint32_t n_front = ra.order && ra.n_front ? *ra.n_front : 0u;      // the slots of the tiles the order put in front for their length
     uint64_t tot_nv = 0, tot_nt = 0;
 #if defined(HVRT_DIAG) && HVRT_DIAG == 32       // a wave's lifetime in the kernel | the clocks it spent inside tiles (16-clock units x 16)
     const long long life0 = clock64();
@@ -1037,6 +1057,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     uint32_t n_done = 0;
 #endif
     unsigned long long wave_cost = 0;     // wave-uniform
+    uint32_t n_walked = 0;                // wave-uniform: tiles this wave walked (all of them without a tile cover)
     uint32_t given_up = 0xFFFFFFFFu;      // wave-uniform: the tile the previous iteration gave up on (see below)
     // The queue head is ONE word, and one word takes about 88 returning atomics per microsecond from the whole chip
     // (MI355X_MICROARCH.md, "dequeue"): 129 600 single-tile pulls cannot finish in under 1.5 ms, whatever the tiles
@@ -1057,7 +1078,10 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #define HVRT_PULL_CLOCKS 200000
 #endif
     constexpr long long PULL_CLOCKS = HVRT_PULL_CLOCKS;
-    constexpr uint32_t MAX_BATCH = 8;
+#ifndef HVRT_MAX_BATCH
+#define HVRT_MAX_BATCH 8
+#endif
+    constexpr uint32_t MAX_BATCH = HVRT_MAX_BATCH;
     // Eight heads (RenderArgs::n_heads), one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 is the
     // XCD's number): behind the first n_waves slots the queue is cut into chunks of HVRT_QUEUE_CHUNK slots, chunk c belongs to
     // head c & 7, and head h hands out the slots of its chunks in order.  The waves of one XCD then work on runs of
@@ -1079,6 +1103,79 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     // of the word's atomic rate, 46 us of waiting for the mean wave, in a 1.7-ms launch.  The head hands out what lies
     // behind those first n_waves slots.
     bool first_pull = true;
+
+    // ---- tiles too long for one wave, sample by sample (RenderArgs::sample_rgb): a supersampled tile is spp independent
+    // pieces of work but for the order in which the pixel's samples are summed.  Every sample of such a tile is an item of
+    // its own; its colours go to a scratch array, and the wave that finishes the tile's last sample sums them in sample
+    // order -- the sum render_pixel forms -- and stores the pixels.  (Tiles past the scratch array's room are items as a
+    // whole.)  An item's first number is the wave's own, like a slot's below.
+    if constexpr (!ABORT) {
+        if (ra.sample_rgb) {
+            const uint32_t n_sp = *ra.n_split, spp_u = (uint32_t)ra.spp;
+            const uint32_t n_by_sample = n_sp < ra.sample_cap ? n_sp : ra.sample_cap;
+            const uint32_t n_items = n_by_sample * spp_u + (n_sp - n_by_sample);
+            uint32_t item = blockIdx.x * RENDER_BLOCK_WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+            while (item < n_items) {
+                const long long clk0 = clock64();
+                const uint32_t sl = item < n_by_sample * spp_u ? item / spp_u : n_by_sample + (item - n_by_sample * spp_u);
+                const int smp = item < n_by_sample * spp_u ? (int)(item - sl * spp_u) : -1;
+                const uint32_t tile = ra.split_tiles[sl];
+                const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
+                const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
+                int x, lr, y;
+                pixel_coords(ra, tx, ty, -1, x, lr, y);
+                const bool inside = x < ra.width && lr < ra.local_rows && y < ra.height;
+                PixelResult px;
+                px.nv = px.nt = 0;
+                if constexpr (INLINE) render_pixel<COUNT, INLINE, NEAREST, 64, false>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, inside, win, 0, px, smp);
+                else if (inside) render_pixel<COUNT, INLINE, NEAREST, 64, false>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, true, nullptr, 0, px, smp);
+                pixel_coords(ra, tx, ty, -1, x, lr, y);
+                if (smp < 0) {
+                    if (inside) store_pixel(ra, fi, lr, x, px);
+                } else {
+                    const size_t p = ((size_t)fi * ra.slab_rows + lr) * ra.width + x;
+                    if (smp == 0 && inside) { if (ra.hit_id) ra.hit_id[p] = px.hit; if (ra.t) ra.t[p] = px.t; }
+                    if (ra.rgb) {
+                        float4* const mine = ra.sample_rgb + ((size_t)sl * spp_u + (uint32_t)smp) * 64u + (uint32_t)lane_now();
+                        __hip_atomic_store(&mine->x, px.rgb.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&mine->y, px.rgb.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&mine->z, px.rgb.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __threadfence();
+                        uint32_t before = 0u;
+                        if (lane_now() == 0) before = __hip_atomic_fetch_add(ra.sample_done + sl, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                        before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
+                        if (before == spp_u - 1u) {
+                            // the tile's last sample: every other sample's colours were released before its count
+                            __threadfence();
+                            V3 acc = { 0.0f, 0.0f, 0.0f };
+                            for (uint32_t k = 0; k < spp_u; ++k) {
+                                const float4* const q = ra.sample_rgb + ((size_t)sl * spp_u + k) * 64u + (uint32_t)lane_now();
+                                const V3 c = { __hip_atomic_load(&q->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                               __hip_atomic_load(&q->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                               __hip_atomic_load(&q->z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) };
+                                acc = k == 0u ? c : add(acc, c);
+                            }
+                            const float n = ra.spp_f;
+                            if (inside) { ra.rgb[3 * p] = acc.x / n; ra.rgb[3 * p + 1] = acc.y / n; ra.rgb[3 * p + 2] = acc.z / n; }
+                            if (lane_now() == 0) __hip_atomic_store(ra.sample_done + sl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the next launch expects it
+                        }
+                    }
+                }
+                const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
+                const uint32_t dc = dt > 0x00FFFFFFull ? 0x00FFFFFFu : (uint32_t)dt;
+                if (lane_now() == 0) atomicAdd(&ra.tile_cost[tile], dc);      // the tile's cost: the sum over its samples (its word holds the bare flag)
+                wave_cost += dc;
+                if (smp <= 0) {
+                    ++n_walked;
+                    if (ra.hits) tot_hits += (uint32_t)__builtin_popcountll(any_lane(inside && px.hit != HVRT_MISS));
+                }
+                if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
+                uint32_t got = 0u;
+                if (lane_now() == 0) got = atomicAdd(ra.tile_counter + 2, 1u);
+                item = n_waves + (uint32_t)__builtin_amdgcn_readlane((int)got, 0);
+            }
+        }
+    }
 
     for (;;) {
         if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
@@ -1118,6 +1215,9 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
                         if (at2 < (unsigned long long)n_queue) { found = true; break; }
                     }
                     head = (head + 1u) & (heads - 1u);
+                    // (another head may still be among its long tiles, whatever this wave's last tiles cost: one at a time
+                    // again -- eight supersampled silhouette tiles in one pull once ended a 7-ms launch at 24 ms)
+                    batch = 1u;
                 }
                 if (!found) break;
             }
@@ -1160,6 +1260,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
         // the give-up deadline runs on the constant 100 MHz clock (s_memrealtime): the shader clock, which prices the
         // tiles, moves with the chip's power state
         const long long wall0 = ABORT ? (long long)wall_clock64() : 0;
+        const unsigned long long debug_wall0 = ra.debug_start ? wall_clock64() : 0ull;      // (a diagnostic: when the tile started, 10-ns ticks)
         const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
         const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
         int x, lr, y;
@@ -1172,14 +1273,42 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
         PixelResult px;
         px.nv = px.nt = 0;
         const bool inside = x < ra.width && lr < ra.local_rows && y < ra.height;
-        if constexpr (INLINE) {
+        // a tile in which, by the cover pass, no sample can hit anything is not walked (the counting kernels walk them all)
+        bool covered = true;
+        if constexpr (!COUNT) {
+            if (ra.cover) {
+                // every lane asks for its own pixel (with row tiles of fewer than eight rows the tile's rows lie in
+                // several tile rows of the frame)
+                uint32_t word = 0u;
+                if (inside) word = ra.cover[(uint64_t)fi * ra.cover_frame_words + (uint64_t)((uint32_t)y >> 3) * ra.cover_words_x + (tx >> 5)];
+                covered = any_lane(((word >> (tx & 31u)) & 1u) != 0u) != 0ull;
+            }
+        }
+        n_walked += covered ? 1u : 0u;
+        if (!covered) {
+            background_pixel(ra, tx, ty, px);
+            if (inside) store_pixel(ra, fi, lr, x, px);
+        } else if constexpr (INLINE) {
             // wave-synchronous walk: lanes outside the image come along without a ray; giving up is wave-wide
 #if defined(HVRT_ABLATE) && HVRT_ABLATE >= 6
             px.rgb = { 0.5f, 0.5f, (float)x }; px.hit = HVRT_MISS; px.t = FLT_MAX;
 #else
+#ifdef HVRT_QUARTER_EXPERIMENT      // timing experiment: every walked tile as four 4x4 quarters, one after the other
+            for (int q = 0; q < 4; ++q) {
+                const int ln = lane_now();
+                const bool mine = inside && ((((ln & 7) >> 2) | ((ln >> 5) << 1)) == q);
+                PixelResult pq; pq.nv = pq.nt = 0;
+                render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, mine, win, wall0, pq);
+                int x2, lr2, y2;
+                pixel_coords(ra, tx, ty, -1, x2, lr2, y2);
+                if (mine) store_pixel(ra, fi, lr2, x2, pq);
+                if (mine) px = pq;
+            }
+#else
             gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, inside, win, wall0, px);
 #endif
-#if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)
+#endif
+#if (!defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)) && !defined(HVRT_QUARTER_EXPERIMENT)
             int x2, lr2, y2;
             pixel_coords(ra, tx, ty, -1, x2, lr2, y2);
             if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr2, x2, px);
@@ -1196,7 +1325,8 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
             const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
             const uint32_t dc = dt > 0x00FFFFFFull ? 0x00FFFFFFu : (uint32_t)dt;
 #if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 5 && HVRT_ABLATE != 7)
-            ra.tile_cost[tile] = dc;      // a dropped tile: k_render_split adds its quads' durations to this
+            ra.tile_cost[tile] = ra.debug_start ? (uint32_t)debug_wall0 : dc;      // a dropped tile: k_render_split adds its quads' durations to this
+            if (!ABORT && ra.debug_start) ra.abandoned[tile] = slot | ((blockIdx.x & 7u) << 28) | (own_slot ? 0x80000000u : 0u);      // (the diagnostic: which slot, whose wave)
 #endif
             wave_cost += dc;
 #if defined(HVRT_DIAG) && HVRT_DIAG == 41
@@ -1212,7 +1342,13 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
             // size of the next pull: PULL_CLOCKS of work at this batch's cost per tile, halved while it exceeds the
             // waves' even share of the slots that are left
             const long long per_tile = (clock64() - batch_clk0) >> __builtin_ctz(batch);     // batch is 1, 2, 4 or 8
+            const uint32_t grown = batch * 2u;
             batch = per_tile * 4 > PULL_CLOCKS ? 1u : per_tile * 8 > PULL_CLOCKS ? 2u : per_tile * 16 > PULL_CLOCKS ? 4u : MAX_BATCH;
+            // One cheap tile says little about the next ones: a pull at most doubles, and among the tiles the order put in front
+            // for their length it stays at one.  (With a tile cover a tile of that kind can turn out not to be walked at all --
+            // its wave then took eight supersampled silhouette tiles in one pull and ended a 7-ms launch at 24 ms.)
+            if (batch > grown) batch = grown;
+            if (n_front && slot < n_front) batch = 1u;
             if (!ra.order && batch > (uint32_t)HVRT_COLD_BATCH) batch = (uint32_t)HVRT_COLD_BATCH;
             const uint32_t left = n_queue > slot ? n_queue - slot : 0u;
             while (batch > 1u && batch * n_waves > left) batch >>= 1;
@@ -1238,6 +1374,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #endif
     const int lane = lane_now();
     if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
+    if (lane == 0 && n_walked && ra.walked) atomicAdd(ra.walked, (unsigned long long)n_walked);
 #if defined(HVRT_DIAG) && HVRT_DIAG == 35
     if (lane == 0 && ra.hits) atomicAdd(ra.hits, wall_clock64() - life_wall0);
 #elif defined(HVRT_DIAG) && HVRT_DIAG == 40     // waves that started more than 0.5 ms behind workgroup 0 (and, << 32, more than 20 us)
@@ -1295,6 +1432,7 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
     const uint32_t tiles_frame = tiles_x * tiles_y;
     if (ra.split_started && threadIdx.x == 0) atomicAdd(ra.split_started, 1u);      // "this workgroup has a place on the GPU"
     const uint32_t n_items = *ra.n_split * 16u;
+    if (ra.walked && blockIdx.x == 0 && threadIdx.x == 0 && n_items) atomicAdd(ra.walked, (unsigned long long)(n_items >> 4));
     const uint32_t wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
     uint64_t tot_nv = 0, tot_nt = 0;
     unsigned long long wave_cost = 0;
@@ -1348,33 +1486,47 @@ __global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra
 //   which is what keeps the L1 / L2 hit rates (a full sort by cost was measured 7 % slower than no order).
 // Stable three-way partition: per-block counts of the first two classes, scan, placement.
 
-__device__ __forceinline__ bool tile_wants_split(uint32_t c, unsigned long long sum, uint32_t slots) {
-    return (c & COST_SPLIT_FLAG) || (unsigned long long)c * slots > sum;
+// (walked: the tiles the launch walked -- with a tile cover most tiles of a frame cost next to nothing, and "the mean tile"
+// is the mean over the walked ones: sum[2], beside the sum of the durations; 0 = not known, all n of them)
+__device__ __forceinline__ uint32_t walked_tiles(const unsigned long long* __restrict__ sum, uint32_t n) {
+    const unsigned long long w = sum[2];
+    return w == 0ull || w > (unsigned long long)n ? n : (uint32_t)w;
 }
-__device__ __forceinline__ int tile_class(uint32_t c, unsigned long long sum, uint32_t n, uint32_t slots, bool may_split) {
-    if (may_split && tile_wants_split(c, sum, slots)) return 2;
-    return (unsigned long long)(c & ~COST_SPLIT_FLAG) * 2ull * n > 5ull * sum ? 1 : 0;      // c > 2.5 * sum / n
+__device__ __forceinline__ bool tile_wants_split(uint32_t c, unsigned long long sum, uint32_t slots_f, uint32_t walked) {
+    const uint32_t slots = slots_f & 0xFFFFFu, f10 = slots_f >> 20;
+    // longer than the balanced launch, and (where the walked tiles are hardly more than the wave slots, so that nearly
+    // every one of them is "longer than the balanced launch") longer than six mean walked tiles
+    return (c & COST_SPLIT_FLAG) || ((unsigned long long)c * slots > sum && (unsigned long long)c * walked * 10ull > (unsigned long long)f10 * sum);
 }
-// block_count: [0, n_blocks] tiles per block that qualify for splitting (allowed or not), [n_blocks + 1,
-// 2 n_blocks + 1] long tiles per block
+// Classes: 3 split, 2 long (more than 2.5 mean WALKED tiles), 1 walked (more than 2.5 x the mean over ALL n tiles: with a
+// tile cover, where most tiles cost next to nothing, that is every walked tile -- they go in front of the cheap ones, and
+// the waves then size their pulls for each kind on its own), 0 the rest.  Without a cover walked == n and class 1 is empty.
+__device__ __forceinline__ int tile_class(uint32_t c, unsigned long long sum, uint32_t n, uint32_t walked, uint32_t slots, bool may_split) {
+    if (may_split && tile_wants_split(c, sum, slots, walked)) return 3;
+    const unsigned long long c2 = (unsigned long long)(c & ~COST_SPLIT_FLAG) * 2ull;
+    return c2 * walked > 5ull * sum ? 2 : (c2 * n > 5ull * sum ? 1 : 0);
+}
+// block_count: three arrays of n_blocks + 1 words: tiles per block that qualify for splitting (allowed or not), long tiles
+// per block, walked tiles per block
 __global__ __launch_bounds__(256) void k_order_count(const uint32_t* __restrict__ cost, uint32_t n,
                                                      const unsigned long long* __restrict__ sum, uint32_t slots,
                                                      bool may_split, uint32_t* __restrict__ block_count) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const bool wants = i < n && tile_wants_split(cost[i], *sum, slots);
-    const int cls = i < n ? tile_class(cost[i], *sum, n, slots, may_split) : 0;
-    __shared__ uint32_t w[2][4];
-    const unsigned long long m2 = __ballot(wants), m1 = __ballot(cls == 1);
-    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = (uint32_t)__popcll(m2); w[1][threadIdx.x >> 6] = (uint32_t)__popcll(m1); }
+    const uint32_t walked = walked_tiles(sum, n);
+    const bool wants = i < n && tile_wants_split(cost[i], *sum, slots, walked);
+    const int cls = i < n ? tile_class(cost[i], *sum, n, walked, slots, may_split) : 0;
+    __shared__ uint32_t w[3][4];
+    const unsigned long long m3 = __ballot(wants), m2 = __ballot(cls == 2), m1 = __ballot(cls == 1);
+    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = (uint32_t)__popcll(m3); w[1][threadIdx.x >> 6] = (uint32_t)__popcll(m2); w[2][threadIdx.x >> 6] = (uint32_t)__popcll(m1); }
     __syncthreads();
-    if (threadIdx.x < 2) block_count[threadIdx.x * (gridDim.x + 1) + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
+    if (threadIdx.x < 3) block_count[threadIdx.x * (gridDim.x + 1) + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
 }
-// each of the two count arrays <- its exclusive scan, [n_blocks] <- its total (one workgroup per array).  The
+// each of the three count arrays <- its exclusive scan, [n_blocks] <- its total (one workgroup per array).  The
 // number of tiles that qualify for splitting goes to *wants_split (pinned host memory, one store; the host reads
 // it, without waiting, to decide whether the NEXT launch gets a k_render_split); when this launch may not split,
 // the first array is cleared instead -- nothing is split.
 __global__ __launch_bounds__(1024) void k_order_scan(uint32_t* __restrict__ block_counts, uint32_t n_blocks, bool may_split,
-                                                     uint32_t* __restrict__ wants_split) {
+                                                     uint32_t* __restrict__ wants_split, uint32_t serial) {
     uint32_t* __restrict__ block_count = block_counts + blockIdx.x * (n_blocks + 1);
     const bool keep = blockIdx.x != 0 || may_split;
     __shared__ uint32_t sh[1024];
@@ -1394,36 +1546,46 @@ __global__ __launch_bounds__(1024) void k_order_scan(uint32_t* __restrict__ bloc
     for (uint32_t i = b; i < e; ++i) { const uint32_t v = block_count[i]; block_count[i] = keep ? run : 0u; run += v; }
     if (threadIdx.x == 1023) {
         block_count[n_blocks] = keep ? sh[1023] : 0u;
-        if (blockIdx.x == 0) *wants_split = sh[1023];
+        // (the count, then the number of the order build it belongs to: a host that reads them in the other order and finds
+        // the number it expects has the count that goes with it)
+        if (blockIdx.x == 0) {
+            __hip_atomic_store(wants_split, sh[1023], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(wants_split + 1, serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
-// order[0, n - n_split): k_render's queue; split_tiles[0, n_split): k_render_split's tiles, whose cost words are
-// reset to the bare flag (that kernel adds its quads' durations to them)
+// order[0, n - n_split): k_render's queue (long tiles, walked tiles, the rest; each in natural order); split_tiles[0,
+// n_split): k_render_split's tiles, whose cost words are reset to the bare flag (that kernel adds its quads' durations
+// to them)
 __global__ __launch_bounds__(256) void k_order_place(uint32_t* __restrict__ cost, uint32_t n,
                                                      const unsigned long long* __restrict__ sum, uint32_t slots, bool may_split,
                                                      const uint32_t* __restrict__ block_count, uint32_t n_blocks,
                                                      uint32_t* __restrict__ order, uint32_t* __restrict__ split_tiles,
                                                      uint32_t* __restrict__ clear_heads, unsigned long long* __restrict__ clear_sum) {
+    // (clear_heads[49], never cleared: the number of long and walked tiles at the queue's head, RenderArgs::n_front)
+    if (blockIdx.x == 0 && threadIdx.x == 26 && clear_heads) clear_heads[49] = block_count[2 * n_blocks + 1] + block_count[3 * n_blocks + 2];
     // (nullable: the 24 queue-head words and the cost sum the NEXT launch starts from -- not the sum read here)
     if (blockIdx.x == 0 && threadIdx.x < 16 && clear_heads) clear_heads[threadIdx.x] = 0u;
     if (blockIdx.x == 0 && threadIdx.x >= 16 && threadIdx.x < 24 && clear_heads) clear_heads[64 + 32 * (threadIdx.x - 16)] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 24 && clear_sum) *clear_sum = 0ull;
+    if (blockIdx.x == 0 && (threadIdx.x == 24 || threadIdx.x == 25) && clear_sum) clear_sum[2 * (threadIdx.x - 24)] = 0ull;      // the sum and its walked count
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const int cls = i < n ? tile_class(cost[i], *sum, n, slots, may_split) : 0;
-    __shared__ uint32_t w[2][4];
-    const unsigned long long m2 = __ballot(cls == 2), m1 = __ballot(cls == 1);
+    const int cls = i < n ? tile_class(cost[i], *sum, n, walked_tiles(sum, n), slots, may_split) : 0;
+    __shared__ uint32_t w[3][4];
+    const unsigned long long m3 = __ballot(cls == 3), m2 = __ballot(cls == 2), m1 = __ballot(cls == 1);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { w[0][wv] = (uint32_t)__popcll(m2); w[1][wv] = (uint32_t)__popcll(m1); }
+    if (lane == 0) { w[0][wv] = (uint32_t)__popcll(m3); w[1][wv] = (uint32_t)__popcll(m2); w[2][wv] = (uint32_t)__popcll(m1); }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t before2 = block_count[blockIdx.x] + (uint32_t)__popcll(m2 & below);
-    uint32_t before1 = block_count[n_blocks + 1 + blockIdx.x] + (uint32_t)__popcll(m1 & below);
-    for (int k = 0; k < wv; ++k) { before2 += w[0][k]; before1 += w[1][k]; }
+    uint32_t before3 = block_count[blockIdx.x] + (uint32_t)__popcll(m3 & below);
+    uint32_t before2 = block_count[n_blocks + 1 + blockIdx.x] + (uint32_t)__popcll(m2 & below);
+    uint32_t before1 = block_count[2 * (n_blocks + 1) + blockIdx.x] + (uint32_t)__popcll(m1 & below);
+    for (int k = 0; k < wv; ++k) { before3 += w[0][k]; before2 += w[1][k]; before1 += w[2][k]; }
     if (i >= n) return;
-    const uint32_t n_long = block_count[2 * n_blocks + 1];
-    if (cls == 2) { split_tiles[before2] = i; cost[i] = COST_SPLIT_FLAG; }
-    else if (cls == 1) order[before1] = i;
-    else order[n_long + (i - before2 - before1)] = i;
+    const uint32_t n_long = block_count[2 * n_blocks + 1], n_walked = block_count[3 * n_blocks + 2];
+    if (cls == 3) { split_tiles[before3] = i; cost[i] = COST_SPLIT_FLAG; }
+    else if (cls == 2) order[before2] = i;
+    else if (cls == 1) order[n_long + before1] = i;
+    else order[n_long + n_walked + (i - before3 - before2 - before1)] = i;
 }
 
 // Slot ranges for a frame rendered as several launches over one queue (RenderArgs::seg_slots): behind the long tiles
@@ -1434,7 +1596,7 @@ __global__ __launch_bounds__(64) void k_order_segments(const uint32_t* __restric
                                                         uint32_t* __restrict__ seg_slots) {
     const int i = (int)threadIdx.x;
     if (i > n_seg) return;
-    const uint32_t n_split = block_count[n_blocks], n_long = block_count[2 * n_blocks + 1];
+    const uint32_t n_split = block_count[n_blocks], n_long = block_count[2 * n_blocks + 1] + block_count[3 * n_blocks + 2];   // long and walked: the queue's head
     const uint32_t n_queue = n_tiles - n_split;
     if (i == 0) { seg_slots[0] = 0; return; }
     if (i == n_seg) { seg_slots[i] = n_queue; return; }
@@ -1617,12 +1779,14 @@ hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s) {
 
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
-                              uint32_t* wants_split, uint32_t* clear_heads, unsigned long long* clear_sum, hipStream_t s) {
+                              uint32_t* wants_split, uint32_t serial, uint32_t* clear_heads, unsigned long long* clear_sum, hipStream_t s) {
     const unsigned blocks = (n_tiles + 255u) / 256u;
-    const uint32_t slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
+    uint32_t slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
+    static const uint32_t f10 = getenv("HVRT_SPLIT_FACTOR_X10") ? (uint32_t)atoi(getenv("HVRT_SPLIT_FACTOR_X10")) : 15u;
+    slots |= f10 << 20;
     may_split = may_split && n_tiles <= 0x0FFFFFFFu;       // 16 items per tile in a 32-bit count
     k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count);
-    k_order_scan<<<2, 1024, 0, s>>>(block_count, blocks, may_split, wants_split);
+    k_order_scan<<<3, 1024, 0, s>>>(block_count, blocks, may_split, wants_split, serial);
     k_order_place<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count, blocks, order, split_tiles, clear_heads, clear_sum);
     return hipGetLastError();
 }

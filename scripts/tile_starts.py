@@ -1,0 +1,54 @@
+"""When the tiles of a launch start: after warm-up launches, one launch records start times instead of durations (HVRT_DEBUG_TILE_START)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import raytracer_amd as ra
+from raytracer_amd import capi, meshgen
+import torch
+which = sys.argv[1]
+tris, g, W, H, spp = {"c2": (meshgen.cube_sphere(289), 256, 3840, 2160, 1), "c4": (meshgen.cube_sphere(289), 256, 7680, 4320, 16)}[which]
+ctx = ra.Context(0); ctx.set_mesh(tris); mn, mx = ctx.mesh_bounds(); vs = capi.voxel_size(mn, mx, g, g, g); ctx.build_grid(g, g, g, mn, mx, vs)
+pos, la, up, fov, asp = capi.default_camera(mn, mx, "front", aspect=W / H)
+cam = capi.make_camera_frame(pos, la, up, fov, asp)
+rgb = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0"); hit = torch.empty((H, W), dtype=torch.int32, device="cuda:0"); t = torch.empty((H, W), dtype=torch.float32, device="cuda:0")
+tx, ty = (W + 7) // 8, (H + 7) // 8
+def launch():
+    ctx.render_part_device(cam, W, H, spp, 1, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0); ctx.synchronize()
+    return ctx.timings().render_ms
+for _ in range(5): ms = launch()
+dur = ctx.tile_costs(tx * ty).astype(np.int64)
+os.environ["HVRT_DEBUG_TILE_START"] = "1"
+ms2 = launch()
+os.environ["HVRT_DEBUG_TILE_START"] = "0"
+st = ctx.tile_costs(tx * ty).astype(np.int64)
+split = (dur >> 31) != 0
+d_us = (dur & 0x7FFFFFFF) * 16 / 2.4e3
+ok = ~split
+st31 = st & 0x7FFFFFFF
+ref = int(np.median(st31[ok]))
+rel = ((st31 - ref + (1 << 30)) % (1 << 31)) - (1 << 30)      # signed distance from the median, wrap-safe
+s_us = (rel - rel[ok].min()) / 100.0
+cov = ctx.tile_cover().reshape(-1)
+w = ok & cov
+print(f"{which}: launch {ms:.2f} ms, the recorded one {ms2:.2f} ms; {int(w.sum())} walked tiles in k_render")
+end = s_us + d_us
+print(f"walked tiles: starts p50 {np.percentile(s_us[w],50):.0f} p90 {np.percentile(s_us[w],90):.0f} p99 {np.percentile(s_us[w],99):.0f} max {s_us[w].max():.0f} us; ends max {end[w].max():.0f} us")
+print(f"skipped tiles: starts p1 {np.percentile(s_us[ok & ~cov],1):.0f} p50 {np.percentile(s_us[ok & ~cov],50):.0f} p99 {np.percentile(s_us[ok & ~cov],99):.0f} max {s_us[ok & ~cov].max():.0f} us")
+# in flight over time
+edges = np.linspace(0, max(end[w].max(), 1), 21)
+for a, b in zip(edges[:-1], edges[1:]):
+    mid = (a + b) / 2
+    print(f"  t={mid:8.0f} us: walked tiles in flight {int(((s_us[w] <= mid) & (end[w] > mid)).sum())}")
+import ctypes as C
+slots = np.zeros(tx * ty, dtype=np.uint32)
+ctx._lib.hvrt_debug_tile_slots.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+assert ctx._lib.hvrt_debug_tile_slots(ctx._h, slots.ctypes.data_as(C.c_void_p), slots.size) == 0
+late = np.argsort(-(s_us * w))[:24]
+print("latest walked starts: (tile x, y) start us, duration us of the launch before, slot, xcd, own")
+for i in late:
+    print(f"   ({i % tx:4d},{i // tx:4d}) {s_us[i]:8.0f} {d_us[i]:8.0f}  slot {slots[i] & 0x0FFFFFFF:7d} xcd {(slots[i] >> 28) & 7} own {slots[i] >> 31}")
+sl = (slots & 0x0FFFFFFF).astype(np.int64)
+print("walked tiles by slot range: slots < 8192:", int((w & (sl < 8192)).sum()), " 8192..40000:", int((w & (sl >= 8192) & (sl < 40000)).sum()), " beyond:", int((w & (sl >= 40000)).sum()))
+b = w & (sl >= 40000)
+if b.any(): print("  walked tiles in slots beyond 40000: durations before us p50", np.percentile(d_us[b], 50), "max", d_us[b].max(), "starts p50", np.percentile(s_us[b], 50))
