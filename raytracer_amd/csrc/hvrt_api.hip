@@ -107,6 +107,7 @@ struct hvrt_ctx {
     uint32_t* abandoned = nullptr; uint64_t abandoned_capacity = 0;
     long long abort_ticks = 100000;     // 1 ms of the constant 100 MHz clock; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
+    hipEvent_t ev_fill_fork = nullptr, ev_fill_join = nullptr;      // k_fill_background runs beside the traversal, on df_stream
     // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
     // Read without waiting -- a stale answer only delays the switch by a launch.  Starts at "some".
     uint32_t* split_hint = nullptr;
@@ -121,6 +122,7 @@ struct hvrt_ctx {
     bool tile_cover = true;
     uint32_t cover_budget = 1024;   // HVRT_TILE_COVER_BUDGET: block tests per triangle before blocks are marked whole
     uint32_t* cover_bits = nullptr; uint64_t cover_capacity = 0;
+    uint32_t* walk_queue = nullptr; uint64_t walk_queue_capacity = 0;      // the marked tiles of a launch, in queue order (launch_compact_queue)
     CoverArgs cover_last = {};     // the last launch that ran the pre-pass (n_frames == 0: none since the scene changed)
     // ... and its cameras: a launch with the same cameras, frame size and mesh finds its cover standing (HVRT_TILE_COVER_CACHE=0:
     // every launch runs the pre-pass)
@@ -482,6 +484,8 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_fill_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&c->ev_fill_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void**)&c->split_hint, 128, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
     c->split_hint[0] = 1u; c->split_hint[1] = 0u;
@@ -576,7 +580,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->df_stream) (void)hipStreamSynchronize(c->df_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->sat_mask, c->cnt16, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
-                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned, c->cover_bits, c->sample_rgb, c->sample_done,
+                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned, c->cover_bits, c->walk_queue, c->sample_rgb, c->sample_done,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
     c->ev[6] = c->ev[7] = nullptr;          // aliases of ring entries
@@ -595,6 +599,8 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_split_fork) (void)hipEventDestroy(c->ev_split_fork);
+    if (c->ev_fill_fork) (void)hipEventDestroy(c->ev_fill_fork);
+    if (c->ev_fill_join) (void)hipEventDestroy(c->ev_fill_join);
     if (c->ev_split_join) (void)hipEventDestroy(c->ev_split_join);
     delete c;
 }
@@ -1184,6 +1190,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     ra.split_tiles = c->split_tiles;
     ra.n_split = c->order_blocks + order_blocks;
     ra.n_front = c->tile_counter + 49;
+    ra.n_queue = nullptr;
     ra.split_started = nullptr;
     ra.abandoned = c->abandoned;
     ra.n_abandoned = c->tile_counter + 1;
@@ -1198,10 +1205,11 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     CoverArgs ca;
     const bool use_cover = c->tile_cover && !d_counters && n_tiles != 0 && scene_of(c).n_tris != 0 &&
                            cover_geometry(width, height, n_frames, scene_of(c).n_tris, ca) == 0;
-    bool cover_stands = false;
+    bool cover_stands = false, fill_beside = false;
     if (use_cover) {
         const uint32_t* const before = c->cover_bits;
         if (int r = ensure<uint32_t>(c, c->cover_bits, c->cover_capacity, cover_words(ca))) return r;
+        if (int r = ensure<uint32_t>(c, c->walk_queue, c->walk_queue_capacity, n_tiles)) return r;
         const CoverArgs& l = c->cover_last;
         cover_stands = c->cover_cache && before == c->cover_bits && l.n_frames == n_frames && l.width == width && l.height == height &&
                        memcmp(c->cover_frames, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames) == 0;
@@ -1219,6 +1227,23 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         }
         ra.cover = ca.bits; ra.cover_words_x = ca.words_x; ra.cover_frame_words = ca.frame_words;
         c->cover_last = ca;
+        // The tiles that are not marked get their pixels here; k_render's queue becomes the marked tiles alone (every slot a
+        // tile to walk, handed out one at a time like before the cover) -- except for a frame in several launches, whose
+        // slot ranges are cut from the full order: there k_render passes the unmarked tiles by as it meets them.
+        const bool in_segments = reuse && plan && plan->n > 1 && plan->n <= 8 && n_frames == 1;
+        uint32_t* const counters = c->tile_counter + 50;      // two words of the queue scratch, zero like the queue's heads
+        // (the fill writes other pixels than the traversal: it runs beside it, on the stream builds use for the distance field)
+        HIP_TRY(c, hipEventRecord(c->ev_fill_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->df_stream, c->ev_fill_fork, 0));
+        HIP_TRY(c, launch_fill_background(ra, c->df_stream));
+        HIP_TRY(c, hipEventRecord(c->ev_fill_join, c->df_stream));
+        fill_beside = true;
+        if (!in_segments) {
+            if (!c->queue_clean) HIP_TRY(c, hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), s));
+            HIP_TRY(c, launch_compact_queue(ra, ra.order, reuse ? ra.n_front : nullptr, c->walk_queue, counters, s));
+            ra.order = c->walk_queue; ra.n_queue = counters; ra.n_front = reuse ? counters + 1 : nullptr;
+            ra.cover = nullptr;
+        }
     } else {
         c->cover_last.n_frames = 0;
     }
@@ -1303,6 +1328,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s));
         }
     }
+    if (fill_beside) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fill_join, 0));
     HIP_TRY(c, hipEventRecord(c->ev[7], s));       // render_ms: the traversal (k_render, and k_render_split beside or behind it)
     // behind the traversal: the order for the next launch of this shape from the durations this one records, and the
     // clean queue head / cost sum that launch starts from
@@ -1311,7 +1337,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         // (its last kernel also clears the queue heads and the next launch's cost sum: two memsets fewer in the stream)
         HIP_TRY(c, launch_order_build(c->tile_cost, (uint32_t)n_tiles, ra.cost_sum, c->n_cus, may_split, c->order_blocks,
                                       c->tile_order, c->split_tiles, c->split_hint_dev, ++c->order_serial, c->tile_counter,
-                                      c->cost_sum + (c->cost_parity ^ 1), s));
+                                      c->cost_sum + (c->cost_parity ^ 1), c->sample_split && spp >= 2 && !d_counters, s));
         c->order_ahead = true;
         c->order_may_split = may_split;
         c->cost_parity ^= 1;
@@ -1321,6 +1347,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         HIP_TRY(c, hipMemsetAsync(c->tile_counter + 64, 0, 8 * 32 * sizeof(uint32_t), s));
         HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity, 0, sizeof(unsigned long long), s));
         HIP_TRY(c, hipMemsetAsync(c->cost_sum + c->cost_parity + 2, 0, sizeof(unsigned long long), s));
+        HIP_TRY(c, hipMemsetAsync(c->tile_counter + 50, 0, 2 * sizeof(uint32_t), s));
     }
     c->queue_clean = true;
     memcpy(c->cost_key, key, sizeof key);

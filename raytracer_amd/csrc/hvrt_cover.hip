@@ -75,7 +75,6 @@
 
 #include <float.h>
 #include <math.h>
-#include <stdlib.h>
 
 namespace hvrt {
 namespace {
@@ -137,16 +136,10 @@ __device__ __forceinline__ void mark(uint32_t* __restrict__ bits, const CoverArg
     const uint32_t nx = x >> k, ny = y >> k;
     uint32_t* const w = bits + ((uint64_t)k * ca.tiles_y + ny) * ca.words_x + (nx >> 5);
     const uint32_t b = 1u << (nx & 31u);
-#ifdef HVRT_COVER_EXPERIMENT
-    if (ca.budget & 0x10000000u) return;
-#endif
     if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) atomicOr(w, b);
 }
 
 __device__ __forceinline__ void or_word(uint32_t* __restrict__ w, uint32_t b, const CoverArgs& ca) {
-#ifdef HVRT_COVER_EXPERIMENT
-    if (ca.budget & 0x10000000u) return;
-#endif
     atomicOr(w, b);       // (no look first: the wave has already put its lanes' bits together, and nothing waits for the result)
 }
 // OR over the 64 lanes (all must be active): two quad swaps, the two row mirrors, then the four rows' values
@@ -306,9 +299,6 @@ __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_re
     }
     if (todo != 2) return;
 
-#ifdef HVRT_COVER_EXPERIMENT
-    if (ca.budget & 0x20000000u) return;
-#endif
     // ---- the block of tiles [x, x + 2^k) x [y, y + 2^k): 0 rejected, 1 survives, 2 lies inside the triangle
     auto block_test = [&](uint32_t x, uint32_t y, uint32_t k) -> int {
         const float half = (float)(4u << k);
@@ -421,13 +411,7 @@ void cover_bind(CoverArgs& ca, uint32_t* words) {
 hipError_t launch_cover(const SceneDev& sc, const CoverArgs& ca, hipStream_t s) {
     if (sc.n_tris == 0 || ca.n_frames < 1) return hipSuccess;
     const dim3 grid((sc.n_tris + 255u) / 256u, (unsigned)ca.n_frames);
-#ifdef HVRT_COVER_EXPERIMENT
-    CoverArgs cx = ca;
-    if (const char* v = getenv("HVRT_COVER_EXPERIMENT")) cx.budget |= (uint32_t)atoi(v) << 28;
-    k_cover<false><<<grid, 256, 0, s>>>(sc.tri_rec, sc.n_tris, cx);
-#else
     k_cover<false><<<grid, 256, 0, s>>>(sc.tri_rec, sc.n_tris, ca);
-#endif
     const dim3 grid_slow((ca.slow_cap + 255u) / 256u, (unsigned)ca.n_frames);
     k_cover<true><<<grid_slow, 256, 0, s>>>(sc.tri_rec, sc.n_tris, ca);
     const uint32_t n_words = ca.tiles_y * ca.words_x;

@@ -70,6 +70,7 @@ struct RenderArgs {
     //   [8 .. 15]    heads of the segment launches (hvrt_render's half frames: launch b uses word 8 + b as ITS [0])
     //   [32 .. 40]   seg_slots: slot ranges of those launches (written by k_order_segments)
     //   [49]         n_front of the order in use (written by the order build, never reset)
+    //   [50], [51]   launch_compact_queue's counters (the queue's length, its front tiles)   zero before a launch
     //   [48]         split_started: workgroups of every k_render_split so far that have started -- compared with a running
     //                total on the host, NEVER reset (hvrt_create zeroes the whole block once)
     //   [64 + 32 h]  head h of the eight per-XCD heads (n_heads == 8), 128 bytes apart so that their atomics do not queue up
@@ -90,6 +91,7 @@ struct RenderArgs {
     // k_render_split, 16 waves per tile (split_tiles[0, *n_split), both written by k_order_place; with order).
     const uint32_t* split_tiles;
     const uint32_t* n_split;
+    const uint32_t* n_queue;      // (nullable) the queue's length, where only the device knows it (launch_compact_queue)
     const uint32_t* n_front;      // (nullable; with order) how many slots at the queue's head hold tiles put there for their length: pulled one at a time
     uint32_t* split_started;      // (nullable) k_render_split: every workgroup adds 1 when it starts (launch_wait_split_started)
     // k_render gives up on a tile whose rays are still inside long lists abort_ticks after they set out and
@@ -187,6 +189,13 @@ hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s);
 // abortable: the kernel may give up on over-long tiles (ra.abandoned); a launch_render_split over that list must follow
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
+// with ra.cover: the pixels of the tiles the cover does not mark (k_render passes those by); in front of launch_render
+hipError_t launch_fill_background(const RenderArgs& ra, hipStream_t s);
+// with ra.cover: queue <- the marked tiles of order_in (null: of the natural order) in nearly that order; counters[0] <- how
+// many, counters[1] <- how many of them from order_in's first *n_front_in slots (both zero on entry); unmarked tiles get a
+// duration of zero.  A launch_render over that queue (order = queue, n_queue = counters, n_front = counters + 1) needs no cover.
+hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* queue,
+                                uint32_t* counters, hipStream_t s);
 hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups = nullptr,
                                uint32_t expected_tiles = 0);
 // One wave that waits (at most timeout_us) until *started has reached `target` (wrap-around compare): queued in front of
@@ -201,7 +210,8 @@ hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsig
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
                               uint32_t* wants_split /* 2 words: the count, then `serial` */, uint32_t serial,
                               uint32_t* clear_heads /* 24 words, nullable */,
-                              unsigned long long* clear_sum /* nullable */, hipStream_t s);
+                              unsigned long long* clear_sum /* nullable */, bool by_sample /* the next launch renders split tiles sample by sample */,
+                              hipStream_t s);
 // seg_slots[0..n_seg] <- the slot ranges of n_seg launches over the queue launch_order_build left: launch b covers the
 // tiles of tile rows [row_bounds[b], row_bounds[b + 1]) that are in k_render's queue behind the long ones; launch 0
 // also takes the long tiles, which sit at the queue's head (row_bounds[0] = 0, row_bounds[n_seg] = tile rows; n_seg <= 8)

@@ -1013,6 +1013,102 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame
     if (ra.t) ra.t[p] = px.t;
 }
 
+// Frame row of row lr of this part's slab (pixel_coords' rule, for any lane or scalar)
+__device__ __forceinline__ int frame_row(const RenderArgs& ra, int lr) {
+    if (ra.n_parts == 1) return lr;
+    const int kl = lr / ra.tile_rows;
+    return (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
+}
+// Does the tile cover mark tile (tx, ty) of frame fi of this part -- any of the frame's tiles its rows lie in?  (With row
+// tiles of a multiple of eight rows, or a single part, the tile's eight rows lie in one tile row of the frame.)
+__device__ __forceinline__ bool tile_covered(const RenderArgs& ra, uint32_t fi, uint32_t tx, uint32_t ty) {
+    const uint32_t* __restrict__ words = ra.cover + (uint64_t)fi * ra.cover_frame_words + (tx >> 5);
+    if (ra.n_parts == 1 || (ra.tile_rows & 7) == 0) {
+        const int y = frame_row(ra, (int)(ty * 8u));
+        return (words[(uint64_t)((uint32_t)y >> 3) * ra.cover_words_x] >> (tx & 31u)) & 1u;
+    }
+    bool any = false;
+    for (int r = 0; r < 8; ++r) {
+        const int lr = (int)(ty * 8u) + r;
+        if (lr >= ra.local_rows) break;
+        const int y = frame_row(ra, lr);
+        if (y < ra.height) any = any || ((words[(uint64_t)((uint32_t)y >> 3) * ra.cover_words_x] >> (tx & 31u)) & 1u);
+    }
+    return any;
+}
+
+// The pixels of the tiles the cover does not mark: the reference's result for a miss (one wave per tile; k_render finds those
+// tiles not marked and passes them by).
+__global__ __launch_bounds__(256) void k_fill_background(RenderArgs ra) {
+    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
+    const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+    const uint32_t tiles_frame = tiles_x * tiles_y;
+    const uint32_t n_tiles = tiles_frame * (uint32_t)ra.n_frames;
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= n_tiles) return;
+    const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
+    const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
+    if (tile_covered(ra, fi, tx, ty)) return;
+    int x, lr, y;
+    pixel_coords(ra, tx, ty, (int)(threadIdx.x & 63u), x, lr, y);
+    PixelResult px;
+    background_pixel(ra, tx, ty, px);
+    if (x < ra.width && lr < ra.local_rows && y < ra.height) store_pixel(ra, fi, lr, x, px);
+}
+
+// Natural order of a launch without history: rows of tiles from the middle of the frame outwards.  The reference's cameras
+// look at the centre of the grid (TraceImages.cpp:125-197), so the silhouette -- where the long tiles are -- surrounds the
+// image centre and starts early.
+__device__ __forceinline__ uint32_t natural_tile(uint32_t sl, uint32_t tiles_x, uint32_t tiles_y) {
+    const uint32_t tiles_frame = tiles_x * tiles_y;
+    const uint32_t fi = sl / tiles_frame, tf = sl - fi * tiles_frame;
+    const uint32_t q = tf / tiles_x, tx = tf - q * tiles_x;
+    const uint32_t mid = tiles_y / 2, h = (q + 1) / 2;
+    const uint32_t ty = (q & 1u) ? (mid >= h ? mid - h : tiles_y - 1 - (h - mid - 1))
+                                 : (mid + h < tiles_y ? mid + h : (tiles_y - 1 - mid) + mid - h);
+    return fi * tiles_frame + ty * tiles_x + tx;
+}
+
+// With a tile cover: k_render's queue is the marked tiles only, in the order they have in order_in (null: the natural order)
+// -- nearly: every wave appends its marked tiles with one atomic, so runs of 64 slots may change places.  counters[0] <- the
+// queue's length, counters[1] <- how many of its tiles come from order_in's first *n_front_in slots (zero on entry);
+// the tiles that are not marked get a duration of zero.
+__global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ n_front_in,
+                                                      uint32_t* __restrict__ queue, uint32_t* __restrict__ counters) {
+    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
+    const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+    const uint32_t tiles_frame = tiles_x * tiles_y;
+    const uint32_t n_tiles = tiles_frame * (uint32_t)ra.n_frames;
+    const uint32_t n_in = order_in ? n_tiles - *ra.n_split : n_tiles;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    bool walk = false;
+    uint32_t tile = 0u;
+    if (slot < n_in) {
+        tile = order_in ? order_in[slot] : natural_tile(slot, tiles_x, tiles_y);
+        if (tile < n_tiles) {
+            const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
+            const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
+            walk = tile_covered(ra, fi, tx, ty);
+            if (!walk && !ra.debug_start) ra.tile_cost[tile] = 0u;
+        }
+    }
+    const unsigned long long m = any_lane(walk);
+    if (m == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u), first = __builtin_ctzll(m);
+    uint32_t base = 0u;
+    if (lane == first) {
+        base = atomicAdd(counters, (uint32_t)__builtin_popcountll(m));
+        const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
+        const uint32_t slot0 = slot - (uint32_t)lane;      // the wave's first slot
+        if (slot0 < nf) {
+            const uint32_t in_front = nf - slot0 >= 64u ? 64u : nf - slot0;
+            atomicAdd(counters + 1, (uint32_t)__builtin_popcountll(in_front >= 64u ? m : (m & ((1ull << in_front) - 1ull))));
+        }
+    }
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
+    if (walk) queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = tile;
+}
+
 // Persistent threads: every wave loops pulling 8x8 pixel tiles until the queue is empty; the
 // exit condition (tile >= n_tiles) is reached by every wave whatever the grid size.
 // ABORT: the variant for launches without tile history (see "gives up" below); launches with history run the
@@ -1033,6 +1129,8 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     __shared__ float4 lds_win[RENDER_BLOCK_WAVES][66];     // per wave: the list chunk its lanes are testing (trace_ray_wave), [64..65] the tile's direction box
     // (the lane number is worked out where it is needed, lane_now(): a register held for it would be spilled)
     float4* const win = lds_win[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
+    __shared__ uint32_t lds_tiles[RENDER_BLOCK_WAVES][64];       // per wave: the tiles of the pull in hand, one per slot
+    uint32_t* const my_tiles = lds_tiles[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))];
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t tiles_frame = tiles_x * tiles_y;
@@ -1040,7 +1138,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     // with an order, the tiles that k_render_split takes are not in this kernel's queue; a launch may be given a
     // range of the queue's slots only (RenderArgs::seg_slots)
     const uint32_t slot0 = ra.seg_slots ? ra.seg_slots[ra.seg] : 0u;
-    const uint32_t n_queue = ra.seg_slots ? ra.seg_slots[ra.seg + 1] : (ra.order ? n_tiles - *ra.n_split : n_tiles);
+    const uint32_t n_queue = ra.n_queue ? *ra.n_queue : ra.seg_slots ? ra.seg_slots[ra.seg + 1] : (ra.order ? n_tiles - *ra.n_split : n_tiles);
     const uint32_t n_front = ra.order && ra.n_front ? *ra.n_front : 0u;      // the slots of the tiles the order put in front for their length
     uint64_t tot_nv = 0, tot_nt = 0;
 #if defined(HVRT_DIAG) && HVRT_DIAG == 32       // a wave's lifetime in the kernel | the clocks it spent inside tiles (16-clock units x 16)
@@ -1082,6 +1180,10 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #define HVRT_MAX_BATCH 8
 #endif
     constexpr uint32_t MAX_BATCH = HVRT_MAX_BATCH;
+    // (with a tile cover most slots hold tiles that are passed by: up to 64 at a time, one per lane; a launch without history
+    // takes its tiles where the image has them, HVRT_COLD_BATCH at a time -- unless most of them are passed by)
+    const uint32_t max_batch = (!COUNT && ra.cover) ? 64u : MAX_BATCH;
+    const uint32_t cold_batch = (!COUNT && ra.cover) ? 16u : (uint32_t)HVRT_COLD_BATCH;
     // Eight heads (RenderArgs::n_heads), one per XCD (workgroups go to the XCDs round-robin, so blockIdx.x & 7 is the
     // XCD's number): behind the first n_waves slots the queue is cut into chunks of HVRT_QUEUE_CHUNK slots, chunk c belongs to
     // head c & 7, and head h hands out the slots of its chunks in order.  The waves of one XCD then work on runs of
@@ -1090,7 +1192,8 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #ifndef HVRT_QUEUE_CHUNK_LOG2
 #define HVRT_QUEUE_CHUNK_LOG2 9
 #endif
-    uint32_t batch = 1, slot = 0, rem = 0, g = 0;     // wave-uniform: `rem` slots of this pull are left; g: the next one's number at its head
+    uint32_t batch = 1, slot = 0, g = 0, g0 = 0;      // wave-uniform: g: the next slot's number at its head, g0: the first one of the pull in hand
+    unsigned long long pend = 0ull;                   // wave-uniform: bit i: slot i of the pull in hand holds a tile that is still to be walked
     const uint32_t heads = ra.n_heads > 1u ? ra.n_heads : 1u;              // a power of two
     // (the eight heads lie 128 bytes apart, tile_counter[64 + 32 h]: atomics on one cache line queue up behind one another)
     uint32_t* const head0 = heads > 1u ? ra.tile_counter + 64 : ra.tile_counter;
@@ -1103,6 +1206,27 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     // of the word's atomic rate, 46 us of waiting for the mean wave, in a 1.7-ms launch.  The head hands out what lies
     // behind those first n_waves slots.
     bool first_pull = true;
+    // slot number g of the wave's current head (its chunks, in order; a head's slots rise with g)
+    auto slot_of = [&](uint32_t gg) -> unsigned long long {
+        return heads > 1u
+            ? (unsigned long long)slot0 + n_waves + ((((unsigned long long)(gg >> HVRT_QUEUE_CHUNK_LOG2) * heads + head) << HVRT_QUEUE_CHUNK_LOG2) | (gg & ((1u << HVRT_QUEUE_CHUNK_LOG2) - 1u)))
+            : (unsigned long long)slot0 + n_waves + gg;
+    };
+    // size of the next pull: PULL_CLOCKS of work at the last pull's cost per slot, halved while it exceeds the waves' even
+    // share of the slots that are left (last: the last slot of the pull that has just been finished)
+    auto size_next_pull = [&](unsigned long long last) {
+        const long long per_tile = (clock64() - batch_clk0) / (long long)batch;
+        const uint32_t grown = batch * 2u;
+        batch = per_tile * 4 > PULL_CLOCKS ? 1u : per_tile * 8 > PULL_CLOCKS ? 2u : per_tile * 16 > PULL_CLOCKS ? 4u : per_tile * 32 > PULL_CLOCKS ? 8u : max_batch;
+        // One cheap tile says little about the next ones: a pull at most doubles, and among the tiles the order put in front
+        // for their length it stays at one.  (With a tile cover a tile of that kind can turn out not to be walked at all --
+        // its wave then took eight supersampled silhouette tiles in one pull and ended a 7-ms launch at 24 ms.)
+        if (batch > grown) batch = grown;
+        if (n_front && last < (unsigned long long)n_front) batch = 1u;
+        if (!ra.order && batch > cold_batch) batch = cold_batch;
+        const unsigned long long left = (unsigned long long)n_queue > last ? (unsigned long long)n_queue - last : 0ull;
+        while (batch > 1u && (unsigned long long)batch * n_waves > left) batch >>= 1;
+    };
 
     // ---- tiles too long for one wave, sample by sample (RenderArgs::sample_rgb): a supersampled tile is spp independent
     // pieces of work but for the order in which the pixel's samples are summed.  Every sample of such a tile is an item of
@@ -1180,7 +1304,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     for (;;) {
         if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
         given_up = 0xFFFFFFFFu;
-        if (rem == 0u) {
+        if (pend == 0ull) {
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31       // clocks spent waiting for the queue head | clocks in the loop, per wave
             const long long pull0 = clock64();
 #endif
@@ -1224,38 +1348,44 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #if defined(HVRT_DIAG) && HVRT_DIAG == 31
             if (COUNT && lane_now() == 0) { tot_nv += (uint64_t)(clock64() - pull0); tot_nt += 1; }
 #endif
-            rem = batch;
             batch_clk0 = clock64();
-        }
-        if (!own_slot) {
-            // slot number g of this head (its chunks, in order); a head's slots rise with g, so the first one past the
-            // queue's end ends the pull
-            const unsigned long long at = heads > 1u
-                ? (unsigned long long)slot0 + n_waves + ((((unsigned long long)(g >> HVRT_QUEUE_CHUNK_LOG2) * heads + head) << HVRT_QUEUE_CHUNK_LOG2) | (g & ((1u << HVRT_QUEUE_CHUNK_LOG2) - 1u)))
-                : (unsigned long long)slot0 + n_waves + g;
-            if (at >= (unsigned long long)n_queue) { rem = 0u; batch = 1u; continue; }
-            slot = (uint32_t)at;
-            ++g;
-        }
-        uint32_t pulled = 0;
-        if (lane_now() == 0) {
-            if (ra.order) {
-                pulled = ra.order[slot];
-            } else {
-                // no history for this shape yet: rows of tiles from the middle of the frame outwards.  The
-                // reference's cameras look at the centre of the grid (TraceImages.cpp:125-197), so the
-                // silhouette -- where the long tiles are -- surrounds the image centre and starts early.
-                const uint32_t fi = slot / tiles_frame, tf = slot - fi * tiles_frame;
-                const uint32_t q = tf / tiles_x, tx = tf - q * tiles_x;
-                const uint32_t mid = tiles_y / 2, h = (q + 1) / 2;
-                const uint32_t ty = (q & 1u) ? (mid >= h ? mid - h : tiles_y - 1 - (h - mid - 1))
-                                             : (mid + h < tiles_y ? mid + h : (tiles_y - 1 - mid) + mid - h);
-                pulled = fi * tiles_frame + ty * tiles_x + tx;
+            // ---- what the pull holds: lane i looks up slot i's tile and, with a tile cover, whether it is marked.  The tiles
+            // that are not (their pixels are k_fill_background's) are passed by here, up to 64 of them at the price of one.
+            const uint32_t ln = (uint32_t)lane_now();
+            const unsigned long long my_at = own_slot ? (unsigned long long)slot : slot_of(g + ln);
+            bool valid = ln < batch && my_at < (unsigned long long)n_queue;
+            uint32_t my_tile = 0xFFFFFFFFu;
+            if (valid) {
+                if (ra.order) {
+                    my_tile = ra.order[my_at];
+                } else {
+                    my_tile = natural_tile((uint32_t)my_at, tiles_x, tiles_y);      // no history for this shape yet
+                }
+            }
+            valid = valid && my_tile < n_tiles;      // (always, with a well-formed order)
+            bool walk = valid;
+            if constexpr (!COUNT) {
+                if (ra.cover && valid) {
+                    const uint32_t fi = my_tile / tiles_frame, tf = my_tile - fi * tiles_frame;
+                    const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
+                    walk = tile_covered(ra, fi, tx, ty);
+                    if (!walk && !ra.debug_start) ra.tile_cost[my_tile] = 0u;
+                }
+            }
+            my_tiles[ln] = my_tile;
+            pend = any_lane(walk);
+            g0 = g;
+            g += batch;
+            if (pend == 0ull) {
+                if (own_slot) continue;      // (its one tile is not walked: on to the queue's heads, one tile at first)
+                size_next_pull(slot_of(g0 + batch - 1u));
+                continue;
             }
         }
-        --rem;
-        const uint32_t tile = (uint32_t)__builtin_amdgcn_readlane((int)pulled, 0);   // wave-uniform (an SGPR)
-        if (tile >= n_tiles) break;      // (never, with a well-formed order: every wave leaves through the queue's end)
+        const uint32_t bit = (uint32_t)__builtin_ctzll(pend);
+        pend &= pend - 1ull;
+        if (!own_slot) slot = (uint32_t)slot_of(g0 + bit);
+        const uint32_t tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)my_tiles[bit]);   // wave-uniform (an SGPR)
         const long long clk0 = clock64();
         // the give-up deadline runs on the constant 100 MHz clock (s_memrealtime): the shader clock, which prices the
         // tiles, moves with the chip's power state
@@ -1273,42 +1403,15 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
         PixelResult px;
         px.nv = px.nt = 0;
         const bool inside = x < ra.width && lr < ra.local_rows && y < ra.height;
-        // a tile in which, by the cover pass, no sample can hit anything is not walked (the counting kernels walk them all)
-        bool covered = true;
-        if constexpr (!COUNT) {
-            if (ra.cover) {
-                // every lane asks for its own pixel (with row tiles of fewer than eight rows the tile's rows lie in
-                // several tile rows of the frame)
-                uint32_t word = 0u;
-                if (inside) word = ra.cover[(uint64_t)fi * ra.cover_frame_words + (uint64_t)((uint32_t)y >> 3) * ra.cover_words_x + (tx >> 5)];
-                covered = any_lane(((word >> (tx & 31u)) & 1u) != 0u) != 0ull;
-            }
-        }
-        n_walked += covered ? 1u : 0u;
-        if (!covered) {
-            background_pixel(ra, tx, ty, px);
-            if (inside) store_pixel(ra, fi, lr, x, px);
-        } else if constexpr (INLINE) {
+        ++n_walked;
+        if constexpr (INLINE) {
             // wave-synchronous walk: lanes outside the image come along without a ray; giving up is wave-wide
 #if defined(HVRT_ABLATE) && HVRT_ABLATE >= 6
             px.rgb = { 0.5f, 0.5f, (float)x }; px.hit = HVRT_MISS; px.t = FLT_MAX;
 #else
-#ifdef HVRT_QUARTER_EXPERIMENT      // timing experiment: every walked tile as four 4x4 quarters, one after the other
-            for (int q = 0; q < 4; ++q) {
-                const int ln = lane_now();
-                const bool mine = inside && ((((ln & 7) >> 2) | ((ln >> 5) << 1)) == q);
-                PixelResult pq; pq.nv = pq.nt = 0;
-                render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, mine, win, wall0, pq);
-                int x2, lr2, y2;
-                pixel_coords(ra, tx, ty, -1, x2, lr2, y2);
-                if (mine) store_pixel(ra, fi, lr2, x2, pq);
-                if (mine) px = pq;
-            }
-#else
             gave_up = !render_pixel<COUNT, INLINE, NEAREST, 64, ABORT>(sc, ra, ra.frames ? ra.frames + fi : nullptr, tx, ty, -1, 0, 0, inside, win, wall0, px);
 #endif
-#endif
-#if (!defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)) && !defined(HVRT_QUARTER_EXPERIMENT)
+#if !defined(HVRT_ABLATE) || (HVRT_ABLATE != 4 && HVRT_ABLATE != 7)
             int x2, lr2, y2;
             pixel_coords(ra, tx, ty, -1, x2, lr2, y2);
             if (inside && (!ABORT || !gave_up)) store_pixel(ra, fi, lr2, x2, px);
@@ -1338,21 +1441,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #endif
             if (ra.hits && !dropped) tot_hits += (uint32_t)__builtin_popcountll(any_lane(inside && px.hit != HVRT_MISS));
         }
-        if (rem == 0u) {
-            // size of the next pull: PULL_CLOCKS of work at this batch's cost per tile, halved while it exceeds the
-            // waves' even share of the slots that are left
-            const long long per_tile = (clock64() - batch_clk0) >> __builtin_ctz(batch);     // batch is 1, 2, 4 or 8
-            const uint32_t grown = batch * 2u;
-            batch = per_tile * 4 > PULL_CLOCKS ? 1u : per_tile * 8 > PULL_CLOCKS ? 2u : per_tile * 16 > PULL_CLOCKS ? 4u : MAX_BATCH;
-            // One cheap tile says little about the next ones: a pull at most doubles, and among the tiles the order put in front
-            // for their length it stays at one.  (With a tile cover a tile of that kind can turn out not to be walked at all --
-            // its wave then took eight supersampled silhouette tiles in one pull and ended a 7-ms launch at 24 ms.)
-            if (batch > grown) batch = grown;
-            if (n_front && slot < n_front) batch = 1u;
-            if (!ra.order && batch > (uint32_t)HVRT_COLD_BATCH) batch = (uint32_t)HVRT_COLD_BATCH;
-            const uint32_t left = n_queue > slot ? n_queue - slot : 0u;
-            while (batch > 1u && batch * n_waves > left) batch >>= 1;
-        }
+        if (pend == 0ull) size_next_pull(own_slot ? slot : slot_of(g0 + batch - 1u));
     }
     if (ABORT && lane_now() == 0 && given_up != 0xFFFFFFFFu) ra.abandoned[atomicAdd(ra.n_abandoned, 1u)] = given_up;
 #if defined(HVRT_DIAG) && HVRT_DIAG == 32
@@ -1492,10 +1581,12 @@ __device__ __forceinline__ uint32_t walked_tiles(const unsigned long long* __res
     const unsigned long long w = sum[2];
     return w == 0ull || w > (unsigned long long)n ? n : (uint32_t)w;
 }
+// (slots_f: the wave slots in the low 20 bits, ten times the second rule's factor above them)
+constexpr uint32_t SPLIT_MEAN_X10 = 15u;      // config 2 with a tile cover, factor 1 / 1.5 / 2 / 3 / 4 / 6: 1.22 / 0.76 / 0.85 / 1.02 / 1.14 / 1.31 ms
 __device__ __forceinline__ bool tile_wants_split(uint32_t c, unsigned long long sum, uint32_t slots_f, uint32_t walked) {
     const uint32_t slots = slots_f & 0xFFFFFu, f10 = slots_f >> 20;
     // longer than the balanced launch, and (where the walked tiles are hardly more than the wave slots, so that nearly
-    // every one of them is "longer than the balanced launch") longer than six mean walked tiles
+    // every one of them is "longer than the balanced launch") longer than one and a half mean walked tiles
     return (c & COST_SPLIT_FLAG) || ((unsigned long long)c * slots > sum && (unsigned long long)c * walked * 10ull > (unsigned long long)f10 * sum);
 }
 // Classes: 3 split, 2 long (more than 2.5 mean WALKED tiles), 1 walked (more than 2.5 x the mean over ALL n tiles: with a
@@ -1564,6 +1655,7 @@ __global__ __launch_bounds__(256) void k_order_place(uint32_t* __restrict__ cost
                                                      uint32_t* __restrict__ clear_heads, unsigned long long* __restrict__ clear_sum) {
     // (clear_heads[49], never cleared: the number of long and walked tiles at the queue's head, RenderArgs::n_front)
     if (blockIdx.x == 0 && threadIdx.x == 26 && clear_heads) clear_heads[49] = block_count[2 * n_blocks + 1] + block_count[3 * n_blocks + 2];
+    if (blockIdx.x == 0 && (threadIdx.x == 27 || threadIdx.x == 28) && clear_heads) clear_heads[50 + (threadIdx.x - 27)] = 0u;      // k_compact_queue's counters
     // (nullable: the 24 queue-head words and the cost sum the NEXT launch starts from -- not the sum read here)
     if (blockIdx.x == 0 && threadIdx.x < 16 && clear_heads) clear_heads[threadIdx.x] = 0u;
     if (blockIdx.x == 0 && threadIdx.x >= 16 && threadIdx.x < 24 && clear_heads) clear_heads[64 + 32 * (threadIdx.x - 16)] = 0u;
@@ -1694,6 +1786,19 @@ uint64_t render_tile_count(int width, int local_rows, int n_frames) {
     return tiles_x * tiles_y * (uint64_t)n_frames;
 }
 
+hipError_t launch_fill_background(const RenderArgs& ra, hipStream_t s) {
+    const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
+    if (n_tiles == 0 || !ra.cover) return hipSuccess;
+    k_fill_background<<<(unsigned)((n_tiles + 3) / 4), 256, 0, s>>>(ra);
+    return hipGetLastError();
+}
+hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* queue, uint32_t* counters, hipStream_t s) {
+    const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
+    if (n_tiles == 0 || !ra.cover) return hipErrorInvalidValue;
+    k_compact_queue<<<(unsigned)((n_tiles + 255) / 256), 256, 0, s>>>(ra, order_in, n_front_in, queue, counters);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s) {
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0) return hipSuccess;
@@ -1779,11 +1884,13 @@ hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s) {
 
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
-                              uint32_t* wants_split, uint32_t serial, uint32_t* clear_heads, unsigned long long* clear_sum, hipStream_t s) {
+                              uint32_t* wants_split, uint32_t serial, uint32_t* clear_heads, unsigned long long* clear_sum, bool by_sample, hipStream_t s) {
     const unsigned blocks = (n_tiles + 255u) / 256u;
     uint32_t slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
-    static const uint32_t f10 = getenv("HVRT_SPLIT_FACTOR_X10") ? (uint32_t)atoi(getenv("HVRT_SPLIT_FACTOR_X10")) : 15u;
-    slots |= f10 << 20;
+    // (tiles rendered sample by sample cost no more than in one piece: the bar is lower)
+    // (config 4, the bar at 1 / 2 / 4 / 8 times the slots: 11.8 / 10.6 / 11.0 / 11.1 ms)
+    if (by_sample) slots *= 2u;
+    slots |= SPLIT_MEAN_X10 << 20;
     may_split = may_split && n_tiles <= 0x0FFFFFFFu;       // 16 items per tile in a 32-bit count
     k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count);
     k_order_scan<<<3, 1024, 0, s>>>(block_count, blocks, may_split, wants_split, serial);
