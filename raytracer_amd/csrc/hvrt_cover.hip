@@ -55,7 +55,8 @@
 //
 // The bounding rectangle.  At a single point the tests above read, with all forms multiplied by the sign of E (so that a
 // hit in front of the eye has D > 0):  the ray is rejected if  f_T := D + S_D < 0  (t test),  or  f_u := U + m D + 3 S_u < 0
-// (for D >= -S_D that is case (-) of u: |D| <= D + 2 S_D and S_D <= S_u), or the same for v or w.  All four are affine in (a, b), so any
+// (for D >= -S_D that is case (-) of u: |D| <= D + 2 S_D and S_D <= S_u), or the same for v or w.  (f_T also takes in the
+// reference's "parallel" exit where that reaches further, see the code.)  All four are affine in (a, b), so any
 // combination h = l_i f_i + l_j f_j with weights >= 0 is affine too, and wherever h < 0 one of the two is negative -- the
 // ray is rejected.  Choosing the weights so that h does not depend on b (l_i = |df_j/db|, l_j = |df_i/db| when the two
 // slopes have opposite signs) gives "every ray with a < bound is rejected" or "... a > bound ..." for ALL b: the left or
@@ -206,8 +207,10 @@ __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_re
     const float inv_w = 1.0f / (float)ca.width, inv_h = 1.0f / (float)ca.height;
 
     // ---- the rectangle of tiles outside which every ray is rejected (see "The bounding rectangle" above)
-    uint32_t tx_lo = 0u, tx_hi = ca.tiles_x - 1u, ty_lo = 0u, ty_hi = ca.tiles_y - 1u;
-    if (todo && esign != 0.0f) {
+    // (where the sign of E is not known -- the eye lies in the triangle's plane, within rounding -- both signs are taken in
+    // turn, each without what the other one covers, and the rectangle is the hull of the two)
+    uint32_t tx_lo = ca.tiles_x, tx_hi = 0u, ty_lo = ca.tiles_y, ty_hi = 0u;      // empty
+    auto rectangle = [&](const float sg) {
         const float m = COVER_MARGIN;
         const float W0 = (D0 - U0) - V0;
         // f_T, f_u, f_v, f_w as c0 + ca a + cb b
@@ -215,9 +218,9 @@ __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_re
         // |D| < p_thr (see rej_par below); the two ranges join when p_thr >= S_D, and then "D < p_thr" says it all
         const float p_thr = (0.99f * FLT_EPSILON - det_round) / det_scale - SD;
         const float t0 = p_thr >= SD ? -p_thr : SD;
-        const float c0[4] = { esign * D0 + t0, esign * (U0 + m * D0) + 3.0f * SU, esign * (V0 + m * D0) + 3.0f * SV, esign * (W0 + m * D0) + 3.0f * SW };
-        const float ka[4] = { esign * Da, esign * (Ua + m * Da), esign * (Va + m * Da), esign * (Wa + m * Da) };
-        const float kb[4] = { esign * Db, esign * (Ub + m * Db), esign * (Vb + m * Db), esign * (Wb + m * Db) };
+        const float c0[4] = { sg * D0 + t0, sg * (U0 + m * D0) + 3.0f * SU, sg * (V0 + m * D0) + 3.0f * SV, sg * (W0 + m * D0) + 3.0f * SW };
+        const float ka[4] = { sg * Da, sg * (Ua + m * Da), sg * (Va + m * Da), sg * (Wa + m * Da) };
+        const float kb[4] = { sg * Db, sg * (Ub + m * Db), sg * (Vb + m * Db), sg * (Wb + m * Db) };
         float mag[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) mag[i] = COVER_PAD * ((fabsf(c0[i]) + fabsf(ka[i])) + fabsf(kb[i]));
@@ -250,15 +253,21 @@ __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_re
         const float wf = (float)ca.width, hf = (float)ca.height;
         const float x_lo = fmaxf(a_lo * wf - 1.0f - (0.015625f + COVER_PAD * 4.0f * wf), 0.0f), x_hi = fminf(a_hi * wf + (0.015625f + COVER_PAD * 4.0f * wf), wf);
         const float y_lo = fmaxf(b_lo * hf - 1.0f - (0.015625f + COVER_PAD * 4.0f * hf), 0.0f), y_hi = fminf(b_hi * hf + (0.015625f + COVER_PAD * 4.0f * hf), hf);
-        if (!(x_lo <= x_hi && y_lo <= y_hi)) {
-            todo = 0;      // no pixel at all
-        } else {
-            tx_lo = (uint32_t)x_lo >> 3; ty_lo = (uint32_t)y_lo >> 3;
-            const uint32_t xh = (uint32_t)x_hi >> 3, yh = (uint32_t)y_hi >> 3;
-            tx_hi = xh < tx_hi ? xh : tx_hi; ty_hi = yh < ty_hi ? yh : ty_hi;
-            if (tx_lo > tx_hi || ty_lo > ty_hi) todo = 0;
-            else if (tx_hi - tx_lo < 4u && ty_hi - ty_lo < 4u) todo = 1;
+        if (x_lo <= x_hi && y_lo <= y_hi) {
+            const uint32_t xl = (uint32_t)x_lo >> 3, yl = (uint32_t)y_lo >> 3;
+            uint32_t xh = (uint32_t)x_hi >> 3, yh = (uint32_t)y_hi >> 3;
+            xh = xh < ca.tiles_x - 1u ? xh : ca.tiles_x - 1u; yh = yh < ca.tiles_y - 1u ? yh : ca.tiles_y - 1u;
+            if (xl <= xh && yl <= yh) {
+                tx_lo = xl < tx_lo ? xl : tx_lo; tx_hi = xh > tx_hi ? xh : tx_hi;
+                ty_lo = yl < ty_lo ? yl : ty_lo; ty_hi = yh > ty_hi ? yh : ty_hi;
+            }
         }
+    };
+    if (todo) rectangle(esign != 0.0f ? esign : 1.0f);
+    if (todo && esign == 0.0f) rectangle(-1.0f);
+    if (todo) {
+        if (tx_lo > tx_hi || ty_lo > ty_hi) todo = 0;      // no pixel at all
+        else if (tx_hi - tx_lo < 4u && ty_hi - ty_lo < 4u) todo = 1;
     }
 
     // ---- the small rectangles of the wave's 64 triangles, put together: neighbouring triangles mark the same few tiles, and
