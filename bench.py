@@ -113,7 +113,10 @@ def render_roofline(prof, k_ms, rays, bytes_per_ray):
     instructions is given beside it.  (Round 2's estimate priced with a static instruction mix exceeded 1 on two
     workloads and is no longer part of the line.)"""
     requested = bytes_per_ray * rays                       # bytes the REFERENCE algorithm asks for, per launch
-    out = {"kernel": "k_render", "kernel_ms": k_ms, "algorithmic_bytes_per_ray": bytes_per_ray,
+    out = {"kernel": "k_render", "kernel_ms": k_ms,
+           "kernel_ms_is": "HIP events around the whole launch on libhvrt's stream: k_render and, beside it, k_render_split and "
+                           "k_fill_background, behind k_compact_queue (and the cover pass when the cover does not stand)",
+           "algorithmic_bytes_per_ray": bytes_per_ray,
            "requested_GBps": requested / (k_ms * 1e-3) / 1e9, "hbm_peak_GBps": 8000.0,
            "live": ["kernel_ms", "requested_GBps", "algorithmic_bytes_per_ray", "hbm_frac (this run's kernel_ms, the profile's bytes)", "reuse_factor"]}
     traffic = prof.get("k_render_hbm_bytes_per_launch")
@@ -128,7 +131,10 @@ def render_roofline(prof, k_ms, rays, bytes_per_ray):
         out.update({"bound": name, "achieved": cands[bound], "peak": 1.0,
                     "unit": "busy clocks of the binding unit per kernel clock", "frac": cands[bound],
                     "frac_is": "a floor (2 clocks per VALU wave-instruction, the guide's figure); static: from the counter passes under "
-                               "profiles/, not measured in this run"})
+                               "profiles/, not measured in this run",
+                    "bound_note": "with the tile cover a frame leaves k_render about as many tiles to walk as the GPU has wave slots: the "
+                                  "launch lasts as long as its longest tiles and no unit is busy for most of it; where every tile is walked "
+                                  "(HVRT_TILE_COVER=0, roofline_no_tile_cover) the same kernel is bound by VALU issue"})
         out["candidates"] = cands
         fp = {k: prof[k] for k in ("valu_issue_frac", "valu_insts_per_launch", "valu_clocks_per_inst_floor", "vector_loads_per_launch",
                                    "vector_loads_per_tile", "kernel_cycles", "l2_hit_rate", "source", "busy_source") if k in prof}
@@ -342,29 +348,36 @@ def main():
     bytes_per_ray = 8.0 * V + 40.0 * T + (12.0 + 8.0) / spp          # +8 because hit id and t are written
     scene.update({"voxels_per_ray": V, "tri_tests_per_ray": T, "hit_fraction": hit_frac})
 
-    cold_ms = unordered_ms = None
+    cold_ms = unordered_ms = no_cover_ms = None
     if world == 1:
         # first launch of a shape (no tile history: the give-up variant + the split kernel behind it), plain kernel
         ctx.build_grid(g, g, g, mn, mx, vs3)                           # a new grid forgets the history
         ctx.render_part_device(cam, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
         ctx.synchronize()
         cold_ms = float(ctx.timings().render_ms)
-        # the same frame with the use of history switched off (HVRT_TILE_ORDER=0 is read when a context is created)
-        os.environ["HVRT_TILE_ORDER"] = "0"
-        try:
-            ctx2 = ra.Context(local_rank)
-        finally:
-            del os.environ["HVRT_TILE_ORDER"]
-        a, o, i = ctx.device_arrays()
-        ctx2.set_mesh_device(a, info.n_triangles)
-        ctx2.set_grid_csr_device(g, g, g, mn, mx, vs3, o, i, info.n_refs)
-        ms = []
-        for _ in range(4):
-            ctx2.render_part_device(cam, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
-            ctx2.synchronize()
-            ms.append(ctx2.timings().render_ms)
-        unordered_ms = float(np.mean(ms[1:]))
-        ctx2.close()
+        # the same frame with nothing carried over from one launch to the next: no tile history (HVRT_TILE_ORDER=0) and the
+        # tile cover worked out again by every launch (HVRT_TILE_COVER_CACHE=0) -- and, separately, without the tile cover at
+        # all (every tile walked, with history: what rounds 1 and 2 measured).  The switches are read when a context is created.
+        def other_context(env, n=4):
+            for k, v in env.items():
+                os.environ[k] = v
+            try:
+                cx = ra.Context(local_rank)
+            finally:
+                for k in env:
+                    del os.environ[k]
+            a, o, i = ctx.device_arrays()
+            cx.set_mesh_device(a, info.n_triangles)
+            cx.set_grid_csr_device(g, g, g, mn, mx, vs3, o, i, info.n_refs)
+            ms = []
+            for _ in range(n):
+                cx.render_part_device(cam, W, H, spp, seed, H, 0, 1, rgb_d.data_ptr(), hit_d.data_ptr(), t_d.data_ptr(), 0)
+                cx.synchronize()
+                ms.append(cx.timings().render_ms)
+            cx.close()
+            return float(np.mean(ms[1:]))
+        unordered_ms = other_context({"HVRT_TILE_ORDER": "0", "HVRT_TILE_COVER_CACHE": "0"})
+        no_cover_ms = other_context({"HVRT_TILE_COVER": "0"}, n=6)
 
     kernel_ms = []
     if world == 1:
@@ -488,10 +501,16 @@ def main():
             k_ms = float(np.mean(kernel_ms))
             out["roofline"] = render_roofline(load_profile(args.workload), k_ms, W * H * spp, bytes_per_ray)
             out["cold_ms"] = cold_ms                     # first launch of the shape, no tile history
-            out["unordered_ms"] = unordered_ms           # HVRT_TILE_ORDER=0: every launch like a first one
+            out["unordered_ms"] = unordered_ms           # HVRT_TILE_ORDER=0, HVRT_TILE_COVER_CACHE=0: every launch like a first one
             out["unordered_Mrays_s"] = W * H * spp / (unordered_ms * 1e-3) / 1e6 if unordered_ms else None
-            # what holds whatever the previous frame was: no tile history at all (`value` is a replay of one camera)
+            # what holds whatever the previous frame was: no tile history, the tile cover worked out by the launch itself
+            # (`value` is a replay of one camera: its tile durations order the queue, its cover stands)
             out["value_unconditional"] = out["unordered_Mrays_s"]
+            out["no_tile_cover_ms"] = no_cover_ms        # HVRT_TILE_COVER=0: every tile walked (with history), as in rounds 1 and 2
+            if no_cover_ms and load_profile(args.workload + "_no_cover"):
+                # the same kernel where it is bound by throughput: every tile walked (its own counter passes, this run's duration)
+                out["roofline_no_tile_cover"] = render_roofline(load_profile(args.workload + "_no_cover"), no_cover_ms, W * H * spp, bytes_per_ray)
+            out["no_tile_cover_Mrays_s"] = W * H * spp / (no_cover_ms * 1e-3) / 1e6 if no_cover_ms else None
             if moving:
                 out["moving_camera"] = moving
         out["roofline_build"] = roof_build

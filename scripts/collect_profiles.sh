@@ -12,6 +12,11 @@ if [ "$step" = pmc ]; then
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_build_c2 build_c2 || exit 1
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c4 render_c4 || exit 1
   $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c3 render_c3 || exit 1
+  # the traversal kernel with every tile walked: where it is bound by throughput
+  export HVRT_TILE_COVER=0
+  $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_no_cover render || exit 1
+  $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c4_no_cover render_c4 || exit 1
+  $GRAFT_REPO_ROOT/scripts/pmc_passes.sh $tag/pmc_render_c3_no_cover render_c3 || exit 1
   exit 0
 fi
 rm -rf $O/kt_bench $O/kt_c3 $O/kt_c4 $O/kt_c5

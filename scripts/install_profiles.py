@@ -115,6 +115,27 @@ if step == "pmc":
                 "vmem_return_frac": round(mw("SQ_INSTS_VMEM_RD") * CLK_WAVE_LOAD_X4 / N_CU / cw, 3),
                 "source": "profiles/" + RND + "_pmc_" + w + ".json, priced like c2 (the hot loops are the same code: profiles/" + RND + "_valu_mix.json)"}
         print(w, {k: v for k, v in t[w].items() if not isinstance(v, str)})
+    # the same kernel with every tile walked (HVRT_TILE_COVER=0): where it is bound by throughput, not by its longest tiles
+    for w, sub, px in (("c2", "pmc_render_no_cover", 3840 * 2160), ("c3", "pmc_render_c3_no_cover", 3840 * 2160), ("c4", "pmc_render_c4_no_cover", 7680 * 4320)):
+        fp = F + "/" + sub + "/summary.json"
+        if not os.path.exists(fp):
+            continue
+        pw = json.load(open(fp))
+        json.dump(pw, open(P + "/" + RND + "_pmc_" + w + "_no_cover.json", "w"), indent=1)
+        kw = [v for n, v in pw.items() if KERNEL in n][0]
+        mw = lambda c: mean_of(kw, c)
+        cw = mw("GRBM_GUI_ACTIVE") / N_XCD
+        t[w + "_no_cover"] = {"kernel": KERNEL + ", HVRT_TILE_COVER=0",
+                "k_render_hbm_bytes_per_launch": (2 * mw("FETCH_SIZE") + mw("WRITE_SIZE")) * 1024,
+                "kernel_cycles": cw, "valu_insts_per_launch": mw("SQ_INSTS_VALU"), "valu_clocks_per_inst": clk_valu,
+                **valu_fracs(mw("SQ_INSTS_VALU"), clk_valu, cw),
+                "salu_issue_frac": round(mw("SQ_INSTS_SALU") / N_CU / cw, 3),
+                "vector_loads_per_launch": mw("SQ_INSTS_VMEM_RD"), "vector_loads_per_tile": mw("SQ_INSTS_VMEM_RD") / (px / 64),
+                "vmem_return_frac": round(mw("SQ_INSTS_VMEM_RD") * CLK_WAVE_LOAD_X4 / N_CU / cw, 3),
+                "source": "profiles/" + RND + "_pmc_" + w + "_no_cover.json: the counter passes with HVRT_TILE_COVER=0 (every tile walked), priced like c2"}
+        if "TCC_HIT_sum" in kw:
+            t[w + "_no_cover"]["l2_hit_rate"] = round(mw("TCC_HIT_sum") / (mw("TCC_HIT_sum") + mw("TCC_MISS_sum")), 3)
+        print(w + "_no_cover", {k: v for k, v in t[w + "_no_cover"].items() if not isinstance(v, str)})
     json.dump(t, open(P + "/traffic.json", "w"), indent=1)
     print(json.dumps({k: v for k, v in c2.items() if not isinstance(v, str)}, indent=0))
     if "c5" in t:
