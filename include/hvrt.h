@@ -148,11 +148,12 @@ int hvrt_render_history(hvrt_ctx* ctx, float* ms, int max_entries);
 /* The tile cover of the last launch without counters (hvrt_cover.hip): before such a launch a pass over the triangles
  * marks the 8x8-pixel tiles of each frame in which some sample's ray can pass the reference's ray / triangle test
  * (GeometryUtils.cpp:57-97) for some triangle; the pixels of the other tiles receive the reference's result for a miss
- * without a walk.  dims <- {tiles per row, rows of tiles, words per row}; bits (nullable; rows x words, bit tx & 31 of
+ * without a walk.  dims <- {tiles per row, rows of tiles, words per row, triangles whose rectangle of tiles was larger than
+ * 4 x 4 (the pass's second kernel handles those)}; bits (nullable; rows x words, bit tx & 31 of
  * word [ty * words + tx / 32], FRAME rows) <- the map of `frame` of that launch.  HVRT_TILE_COVER=0 turns the pass off
  * (then, and after a launch with counters, HVRT_ERR_INVALID).  Waits for the stream.  No reference counterpart
  * (OctreeLikeRayTracer.cpp:88-126 walks every ray). */
-int hvrt_get_tile_cover(hvrt_ctx* ctx, int frame, uint32_t* bits, uint64_t capacity_words, uint32_t dims[3]);
+int hvrt_get_tile_cover(hvrt_ctx* ctx, int frame, uint32_t* bits, uint64_t capacity_words, uint32_t dims[4]);
 /* The durations the last asynchronous traversal recorded for its 8x8-pixel tiles, in units of 16 shader clocks, tile
  * t = (frame * rows of tiles + row) * tiles per row + column of the rendered PART (what the next launch of the same shape
  * orders its work queue by; top bit: the tile is rendered by the 16-wave kernel, the word then holds the sum over its

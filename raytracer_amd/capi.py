@@ -411,9 +411,10 @@ class Context:
     def tile_cover(self, frame: int = 0) -> np.ndarray:
         """The tile cover of the last launch without counters: a bool array (rows of tiles, tiles per row), row 0 = the
         frame's row 0; True where the tile was walked."""
-        dims = (C.c_uint32 * 3)()
+        dims = (C.c_uint32 * 4)()
         self._ck(self._lib.hvrt_get_tile_cover(self._h, frame, None, 0, dims))
         tx, ty, wx = int(dims[0]), int(dims[1]), int(dims[2])
+        self.last_cover_general_case = int(dims[3])      # triangles the pass's second kernel handled
         words = np.zeros(ty * wx, dtype=np.uint32)
         self._ck(self._lib.hvrt_get_tile_cover(self._h, frame, words.ctypes.data_as(C.c_void_p), words.size, dims))
         bits = np.unpackbits(words.view(np.uint8).reshape(ty, wx * 4), axis=1, bitorder="little")

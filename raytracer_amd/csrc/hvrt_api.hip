@@ -1402,13 +1402,15 @@ int hvrt_download_blocks(hvrt_ctx* c, void* dst, const void* d_src, uint64_t byt
     return hvrt_synchronize(c);
 }
 
-int hvrt_get_tile_cover(hvrt_ctx* c, int frame, uint32_t* bits, uint64_t capacity_words, uint32_t dims[3]) {
+int hvrt_get_tile_cover(hvrt_ctx* c, int frame, uint32_t* bits, uint64_t capacity_words, uint32_t dims[4]) {
     if (!c || !dims) return HVRT_ERR_INVALID;
     if (int r = bind(c)) return r;
     const CoverArgs& ca = c->cover_last;
     if (ca.n_frames < 1) return fail(c, HVRT_ERR_INVALID, "tile cover: the last launch ran without the pre-pass (counters, HVRT_TILE_COVER=0) or there was none");
     if (frame < 0 || frame >= ca.n_frames) return fail(c, HVRT_ERR_INVALID, "tile cover: frame %d outside 0..%d", frame, ca.n_frames - 1);
     dims[0] = ca.tiles_x; dims[1] = ca.tiles_y; dims[2] = ca.words_x;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(&dims[3], ca.slow_count + frame, sizeof(uint32_t), hipMemcpyDeviceToHost));
     const uint64_t n = (uint64_t)ca.tiles_y * ca.words_x;
     if (!bits) return HVRT_OK;
     if (capacity_words < n) return fail(c, HVRT_ERR_INVALID, "tile cover: %llu words needed, %llu given", (unsigned long long)n, (unsigned long long)capacity_words);

@@ -137,7 +137,7 @@ __device__ __forceinline__ void mark(uint32_t* __restrict__ bits, const CoverArg
     const uint32_t nx = x >> k, ny = y >> k;
     uint32_t* const w = bits + ((uint64_t)k * ca.tiles_y + ny) * ca.words_x + (nx >> 5);
     const uint32_t b = 1u << (nx & 31u);
-    if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) atomicOr(w, b);
+    atomicOr(w, b);       // (no look first: a wave that waits for the answer before every mark spends its time waiting)
 }
 
 __device__ __forceinline__ void or_word(uint32_t* __restrict__ w, uint32_t b, const CoverArgs& ca) {

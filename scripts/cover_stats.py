@@ -42,6 +42,7 @@ h = (hit.cpu().numpy() != -1)
 ty, tx = cov.shape
 hp = np.zeros((ty * 8, tx * 8), bool); hp[:H, :W] = h
 ht = hp.reshape(ty, 8, tx, 8).any(axis=(1, 3))
+print("triangles in the general case:", ctx.last_cover_general_case)
 print(f"tiles {tx} x {ty}: marked {cov.mean():.4f}, with a hit {ht.mean():.4f}, hit outside the cover: {int((ht & ~cov).sum())}", flush=True)
 rows = cov.sum(axis=1)
 print("marked per row of tiles (every 16th):", rows[::16].tolist())
