@@ -120,7 +120,6 @@ struct hvrt_ctx {
     // tile cover (hvrt_cover.hip): a pre-pass over the triangles in front of every launch without counters marks the tiles in
     // which a ray can hit something; k_render does not walk the others.  HVRT_TILE_COVER=0 walks every tile.
     bool tile_cover = true;
-    uint32_t cover_budget = 1024;   // HVRT_TILE_COVER_BUDGET: block tests per triangle before blocks are marked whole
     uint32_t* cover_bits = nullptr; uint64_t cover_capacity = 0;
     uint32_t* walk_queue = nullptr; uint64_t walk_queue_capacity = 0;      // the marked tiles of a launch, in queue order (launch_compact_queue)
     CoverArgs cover_last = {};     // the last launch that ran the pre-pass (n_frames == 0: none since the scene changed)
@@ -515,7 +514,6 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if (const char* v = getenv("HVRT_TILE_COVER")) c->tile_cover = atoi(v) != 0;
     if (const char* v = getenv("HVRT_TILE_COVER_CACHE")) c->cover_cache = atoi(v) != 0;
     if (const char* v = getenv("HVRT_SAMPLE_SPLIT")) c->sample_split = atoi(v) != 0;
-    if (const char* v = getenv("HVRT_TILE_COVER_BUDGET")) { const int b = atoi(v); if (b >= 1) c->cover_budget = (uint32_t)b; }
     if (const char* v = getenv("HVRT_HISTORY_MAX_DEG")) c->history_max_rad = (float)atof(v) * 3.14159265f / 180.0f;
     if (const char* v = getenv("HVRT_TILE_ABORT_US")) {
         const long long us = atoll(v);
@@ -1219,7 +1217,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     if (use_cover) {
         // (inside the timed region: render_ms is the pre-pass and the traversal)
         ca.frames = ds; ca.frame0 = frames[0];
-        cover_bind(ca, c->cover_bits); ca.budget = c->cover_budget;
+        cover_bind(ca, c->cover_bits);
         if (!cover_stands) {
             HIP_TRY(c, hipMemsetAsync(ca.bits, 0, cover_zero_words(ca) * sizeof(uint32_t), s));
             HIP_TRY(c, launch_cover(scene_of(c), ca, s));

@@ -66,12 +66,11 @@
 // weights need not be exact (any weights >= 0 give a valid h; what is left of the slope in b and the roundings of the
 // combination are added to h before the bound is taken).  Most triangles of a fine mesh end here, with one to four tiles.
 //
-// Traversal.  Where the rectangle is larger than 2 x 2 tiles (large, close or grazing triangles) the lane walks the
-// quadtree of tile blocks below the smallest block that holds the rectangle, in Z order without a stack, descending only
-// into blocks that meet the rectangle and survive the block test; a surviving tile is marked in level 0 of a bit
-// pyramid.  A block that lies inside the triangle, or any surviving block once the lane has spent its budget of tests,
-// is marked at ITS level instead (one bit; big triangles end early), and k_cover_finish ORs every level down into
-// level 0, the bitmap k_render reads.
+// Marking.  A rectangle of at most 4 x 4 tiles is marked as it is (most triangles of a fine mesh end there: the wave's
+// lanes put their bits together first and one lane marks for all).  Larger rectangles -- large, close or grazing
+// triangles -- are queued for a second kernel that gives each a whole wave: lane i tests tile i of the rectangle with the
+// block form of the test above, 64 tiles at a time; a rectangle of more than 4096 tiles is tested in blocks of 2^k x 2^k
+// tiles and marked at that level of a bit pyramid, which k_cover_finish ORs down into level 0, the bitmap k_render reads.
 #include "hvrt_internal.hpp"
 
 #include <float.h>
@@ -153,32 +152,11 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
                       __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
 }
 
-// SLOW = false: one lane per triangle; the triangles that need the general case are appended to the frame's queue (as far
-// as it has room).  SLOW = true: one lane per queue entry -- the general case with all lanes of a wave at work instead of
-// the one or two in 64 whose rectangle is large.
+// SLOW = false: one lane per triangle; the triangles whose rectangle is larger than 4 x 4 tiles are appended to the frame's
+// queue (as far as it has room).  SLOW = true: one WAVE per queue entry, its lanes share out the rectangle's tiles.
 template <bool SLOW>
-__global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_rec, uint32_t n_tris, CoverArgs ca) {
-    __shared__ FrameConsts fc_s;
-    const uint32_t fi = blockIdx.y;
-    uint32_t n_queued = 0u;
-    if (SLOW) {
-        n_queued = ca.slow_count[fi];
-        if (n_queued > ca.slow_cap) n_queued = ca.slow_cap;
-        if (blockIdx.x * 256u >= n_queued) return;
-    }
-    if (threadIdx.x == 0) frame_consts(ca.frames ? ca.frames[fi] : ca.frame0, fc_s);
-    __syncthreads();
-    uint32_t* const bits = ca.bits + (uint64_t)fi * ca.frame_words;
-    const uint32_t L = (uint32_t)ca.levels;
-    if (!fc_s.ok) {
-        if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) mark(bits, ca, L, 0u, 0u);
-        return;
-    }
-    // (no lane leaves before the wave has put its marks together, below; a lane without a triangle computes on another's)
-    const uint32_t own = blockIdx.x * 256u + threadIdx.x;
-    const bool have = SLOW ? own < n_queued : own < n_tris;
-    uint32_t tri = have ? own : n_tris - 1u;
-    if (SLOW) { tri = have ? ca.slow_queue[(uint64_t)fi * ca.slow_cap + own] : 0u; if (tri >= n_tris) tri = n_tris - 1u; }
+__device__ __forceinline__ void cover_triangle(const float4* __restrict__ tri_rec, const CoverArgs& ca, const FrameConsts& fc_s,
+                                               uint32_t* __restrict__ bits, uint32_t L, uint32_t fi, uint32_t tri, bool have) {
     // what is left to do for this lane's triangle: 0 nothing, 1 the tiles of a rectangle of at most 4 x 4, 2 the general case
     int todo = have ? 2 : 0;
     const F3 A = fc_s.A, hor = fc_s.hor, ver = fc_s.ver;
@@ -308,8 +286,8 @@ __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_re
     }
     if (todo != 2) return;
 
-    // ---- the block of tiles [x, x + 2^k) x [y, y + 2^k): 0 rejected, 1 survives, 2 lies inside the triangle
-    auto block_test = [&](uint32_t x, uint32_t y, uint32_t k) -> int {
+    // ---- may a ray through the block of tiles [x, x + 2^k) x [y, y + 2^k) hit the triangle?
+    auto block_test = [&](uint32_t x, uint32_t y, uint32_t k) -> bool {
         const float half = (float)(4u << k);
         const float ca_ = ((float)(x * 8u) + half) * inv_w, cb_ = ((float)(y * 8u) + half) * inv_h;
         // (padded against the roundings of x / W here and in k_render: 2^-20 of the largest coordinate in play)
@@ -330,39 +308,58 @@ __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_re
         const bool rej_w = (cW - rW > mw && -cUV - rUV > mw) || (cW + rW < -mw && -cUV + rUV < -mw);
         const bool rej_par = (maxD + SD) * det_scale + det_round < 0.99f * FLT_EPSILON;
         const bool rej_t = esign != 0.0f && esign * cD + rD < -SD;
-        if (rej_u || rej_v || rej_w || rej_par || rej_t) return 0;
-        // inside (a heuristic, nothing depends on it but where the marking stops): D keeps its sign and u, v, w >= 0
-        const float sg = cD < 0.0f ? -1.0f : 1.0f;
-        return (fabsf(cD) > rD && sg * cU - rU >= 0.0f && sg * cV - rV >= 0.0f && sg * cW - rW >= 0.0f) ? 2 : 1;
+        return !(rej_u || rej_v || rej_w || rej_par || rej_t);
     };
-    if ((tx_hi - tx_lo + 1u) * (ty_hi - ty_lo + 1u) <= 36u && tx_hi - tx_lo < 36u) {
-        // a small rectangle: tile by tile
-        for (uint32_t yy = ty_lo; yy <= ty_hi; ++yy)
-            for (uint32_t xx = tx_lo; xx <= tx_hi; ++xx)
-                if (block_test(xx, yy, 0u)) mark(bits, ca, 0u, xx, yy);
+    // the rectangle in blocks of 2^k x 2^k tiles, k the smallest for which there are at most `room` of them
+    const uint32_t room = SLOW ? 4096u : 64u;
+    uint32_t k = 0u;
+    while (((tx_hi >> k) - (tx_lo >> k) + 1u) * ((ty_hi >> k) - (ty_lo >> k) + 1u) > room) ++k;
+    const uint32_t bx0 = tx_lo >> k, by0 = ty_lo >> k, bw = (tx_hi >> k) - bx0 + 1u, n_blocks = bw * ((ty_hi >> k) - by0 + 1u);
+    if (SLOW) {
+        // the wave's triangle: lane i takes blocks i, i + 64, ...
+        for (uint32_t t = threadIdx.x & 63u; t < n_blocks; t += 64u) {
+            const uint32_t bx = bx0 + t % bw, by = by0 + t / bw;
+            if (block_test(bx << k, by << k, k)) mark(bits, ca, k, bx << k, by << k);
+        }
+    } else {
+        // (the queue was full: the lane's triangle, block by block)
+        for (uint32_t t = 0; t < n_blocks; ++t) {
+            const uint32_t bx = bx0 + t % bw, by = by0 + t / bw;
+            if (block_test(bx << k, by << k, k)) mark(bits, ca, k, bx << k, by << k);
+        }
+    }
+}
+
+template <bool SLOW>
+__global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_rec, uint32_t n_tris, CoverArgs ca) {
+    __shared__ FrameConsts fc_s;
+    const uint32_t fi = blockIdx.y;
+    uint32_t n_queued = 0u;
+    if (SLOW) {
+        n_queued = ca.slow_count[fi];
+        if (n_queued > ca.slow_cap) n_queued = ca.slow_cap;
+        if (blockIdx.x * 4u >= n_queued) return;
+    }
+    if (threadIdx.x == 0) frame_consts(ca.frames ? ca.frames[fi] : ca.frame0, fc_s);
+    __syncthreads();
+    uint32_t* const bits = ca.bits + (uint64_t)fi * ca.frame_words;
+    const uint32_t L = (uint32_t)ca.levels;
+    if (!fc_s.ok) {
+        if (!SLOW && blockIdx.x == 0 && threadIdx.x == 0) mark(bits, ca, L, 0u, 0u);
         return;
     }
-
-    // ---- the quadtree below the smallest block that holds the rectangle
-    const uint32_t span = (tx_lo ^ tx_hi) | (ty_lo ^ ty_hi);
-    const uint32_t top = span ? 32u - (uint32_t)__builtin_clz(span) : 0u;        // <= L
-    uint32_t k = top, x = (tx_lo >> top) << top, y = (ty_lo >> top) << top, visits = 0u;
-    for (;;) {
-        int verdict = 0;
-        const uint32_t side = 1u << k;
-        if (x <= tx_hi && x + side > tx_lo && y <= ty_hi && y + side > ty_lo) { ++visits; verdict = block_test(x, y, k); }
-        if (verdict == 1 && k > 0u && visits < ca.budget) { --k; continue; }      // into its first child (same corner)
-        if (verdict != 0) mark(bits, ca, k, x, y);
-        // ---- the next block in Z order
-        bool done = false;
-        for (;;) {
-            if (k == top) { done = true; break; }
-            const uint32_t bx = (x >> k) & 1u, by = (y >> k) & 1u, step = 1u << k;
-            if (!bx) { x += step; break; }
-            if (!by) { x -= step; y += step; break; }
-            x -= step; y -= step; ++k;        // the last of four: back to the parent, which is finished too
+    if (SLOW) {
+        // a wave per queue entry (all 64 lanes work out the same triangle), the grid's waves striding over the queue
+        for (uint32_t own = blockIdx.x * 4u + (threadIdx.x >> 6); own < n_queued; own += gridDim.x * 4u) {
+            uint32_t tri = ca.slow_queue[(uint64_t)fi * ca.slow_cap + own];
+            if (tri >= n_tris) tri = n_tris - 1u;
+            cover_triangle<true>(tri_rec, ca, fc_s, bits, L, fi, tri, true);
         }
-        if (done) break;
+    } else {
+        // a lane per triangle (no lane leaves before the wave has put its marks together; a lane without a triangle computes
+        // on the last one)
+        const uint32_t own = blockIdx.x * 256u + threadIdx.x;
+        cover_triangle<false>(tri_rec, ca, fc_s, bits, L, fi, own < n_tris ? own : n_tris - 1u, own < n_tris);
     }
 }
 
@@ -421,7 +418,8 @@ hipError_t launch_cover(const SceneDev& sc, const CoverArgs& ca, hipStream_t s) 
     if (sc.n_tris == 0 || ca.n_frames < 1) return hipSuccess;
     const dim3 grid((sc.n_tris + 255u) / 256u, (unsigned)ca.n_frames);
     k_cover<false><<<grid, 256, 0, s>>>(sc.tri_rec, sc.n_tris, ca);
-    const dim3 grid_slow((ca.slow_cap + 255u) / 256u, (unsigned)ca.n_frames);
+    const uint32_t slow_blocks = (ca.slow_cap + 3u) / 4u;      // a wave per queue entry, at most 2048 workgroups striding over the queue
+    const dim3 grid_slow(slow_blocks < 2048u ? slow_blocks : 2048u, (unsigned)ca.n_frames);
     k_cover<true><<<grid_slow, 256, 0, s>>>(sc.tri_rec, sc.n_tris, ca);
     const uint32_t n_words = ca.tiles_y * ca.words_x;
     const dim3 grid2((n_words + 255u) / 256u, (unsigned)ca.n_frames);

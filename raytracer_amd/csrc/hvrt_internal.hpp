@@ -237,9 +237,8 @@ struct CoverArgs {
     uint32_t* slow_count;              // n_frames words, ZERO on entry: triangles queued for the general case, per frame
     uint32_t* slow_queue;              // n_frames x slow_cap triangle indices
     uint32_t slow_cap;
-    uint32_t budget;                   // block tests per triangle before it marks blocks whole
 };
-// fills in the geometry fields (everything but frames / frame0 / the pointers / budget); nonzero: the frame is too large for a pyramid
+// fills in the geometry fields (everything but frames / frame0 / the pointers); nonzero: the frame is too large for a pyramid
 int cover_geometry(int width, int height, int n_frames, uint32_t n_tris, CoverArgs& ca);
 // one allocation of cover_words(ca) words holds everything: cover_bind points bits / slow_count / slow_queue into it; its
 // first cover_zero_words(ca) words must be zero before launch_cover

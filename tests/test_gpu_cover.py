@@ -209,7 +209,6 @@ def test_cover_follows_the_mesh_under_a_camera_that_stands(ctx):
 
 
 @pytest.mark.parametrize("env", [{"HVRT_TILE_COVER": "0"}, {"HVRT_TILE_COVER_CACHE": "0"}, {"HVRT_SAMPLE_SPLIT": "0"},
-                                 {"HVRT_TILE_COVER_BUDGET": "1"}, {"HVRT_TILE_COVER_BUDGET": "7", "HVRT_TILE_ORDER": "0"},
                                  {"HVRT_TILE_SPLIT": "0"}, {"HVRT_TILE_ORDER": "0"}, {"HVRT_WARMUP": "0", "HVRT_TILE_ABORT_US": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_plain_launches_under_the_switches(monkeypatch, env):
