@@ -68,8 +68,8 @@
 //
 // Marking.  A rectangle of at most 4 x 4 tiles is marked as it is (most triangles of a fine mesh end there: the wave's
 // lanes put their bits together first and one lane marks for all).  Larger rectangles -- large, close or grazing
-// triangles -- are queued for a second kernel that gives each a whole wave: lane i tests tile i of the rectangle with the
-// block form of the test above, 64 tiles at a time; a rectangle of more than 4096 tiles is tested in blocks of 2^k x 2^k
+// triangles -- are queued for a second kernel that gives each sixteen lanes: lane i tests tile i of the rectangle with the
+// block form of the test above, 16 tiles at a time; a rectangle of more than 1024 tiles is tested in blocks of 2^k x 2^k
 // tiles and marked at that level of a bit pyramid, which k_cover_finish ORs down into level 0, the bitmap k_render reads.
 #include "hvrt_internal.hpp"
 
@@ -153,7 +153,7 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
 }
 
 // SLOW = false: one lane per triangle; the triangles whose rectangle is larger than 4 x 4 tiles are appended to the frame's
-// queue (as far as it has room).  SLOW = true: one WAVE per queue entry, its lanes share out the rectangle's tiles.
+// queue (as far as it has room).  SLOW = true: sixteen lanes per queue entry, which share out the rectangle's tiles.
 template <bool SLOW>
 __device__ __forceinline__ void cover_triangle(const float4* __restrict__ tri_rec, const CoverArgs& ca, const FrameConsts& fc_s,
                                                uint32_t* __restrict__ bits, uint32_t L, uint32_t fi, uint32_t tri, bool have) {
@@ -311,13 +311,13 @@ __device__ __forceinline__ void cover_triangle(const float4* __restrict__ tri_re
         return !(rej_u || rej_v || rej_w || rej_par || rej_t);
     };
     // the rectangle in blocks of 2^k x 2^k tiles, k the smallest for which there are at most `room` of them
-    const uint32_t room = SLOW ? 4096u : 64u;
+    const uint32_t room = SLOW ? 1024u : 64u;
     uint32_t k = 0u;
     while (((tx_hi >> k) - (tx_lo >> k) + 1u) * ((ty_hi >> k) - (ty_lo >> k) + 1u) > room) ++k;
     const uint32_t bx0 = tx_lo >> k, by0 = ty_lo >> k, bw = (tx_hi >> k) - bx0 + 1u, n_blocks = bw * ((ty_hi >> k) - by0 + 1u);
     if (SLOW) {
-        // the wave's triangle: lane i takes blocks i, i + 64, ...
-        for (uint32_t t = threadIdx.x & 63u; t < n_blocks; t += 64u) {
+        // the sixteen lanes' triangle: lane i of them takes blocks i, i + 16, ...
+        for (uint32_t t = threadIdx.x & 15u; t < n_blocks; t += 16u) {
             const uint32_t bx = bx0 + t % bw, by = by0 + t / bw;
             if (block_test(bx << k, by << k, k)) mark(bits, ca, k, bx << k, by << k);
         }
@@ -330,18 +330,22 @@ __device__ __forceinline__ void cover_triangle(const float4* __restrict__ tri_re
     }
 }
 
+// the frames' constants, once per launch (double-precision square roots and divides: not once per workgroup)
+__global__ __launch_bounds__(64) void k_cover_frames(CoverArgs ca) {
+    const uint32_t fi = blockIdx.x * 64u + threadIdx.x;
+    if (fi < (uint32_t)ca.n_frames) frame_consts(ca.frames ? ca.frames[fi] : ca.frame0, reinterpret_cast<FrameConsts*>(ca.consts)[fi]);
+}
+
 template <bool SLOW>
 __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_rec, uint32_t n_tris, CoverArgs ca) {
-    __shared__ FrameConsts fc_s;
     const uint32_t fi = blockIdx.y;
     uint32_t n_queued = 0u;
     if (SLOW) {
         n_queued = ca.slow_count[fi];
         if (n_queued > ca.slow_cap) n_queued = ca.slow_cap;
-        if (blockIdx.x * 4u >= n_queued) return;
+        if (blockIdx.x * 16u >= n_queued) return;
     }
-    if (threadIdx.x == 0) frame_consts(ca.frames ? ca.frames[fi] : ca.frame0, fc_s);
-    __syncthreads();
+    const FrameConsts& fc_s = reinterpret_cast<const FrameConsts*>(ca.consts)[fi];
     uint32_t* const bits = ca.bits + (uint64_t)fi * ca.frame_words;
     const uint32_t L = (uint32_t)ca.levels;
     if (!fc_s.ok) {
@@ -349,11 +353,13 @@ __global__ __launch_bounds__(256) void k_cover(const float4* __restrict__ tri_re
         return;
     }
     if (SLOW) {
-        // a wave per queue entry (all 64 lanes work out the same triangle), the grid's waves striding over the queue
-        for (uint32_t own = blockIdx.x * 4u + (threadIdx.x >> 6); own < n_queued; own += gridDim.x * 4u) {
-            uint32_t tri = ca.slow_queue[(uint64_t)fi * ca.slow_cap + own];
+        // sixteen lanes per queue entry (they work out the same triangle and share out its rectangle's tiles), four entries per
+        // wave, the grid's waves striding over the queue
+        for (uint32_t first = (blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u; first < n_queued; first += gridDim.x * 16u) {
+            const uint32_t own = first + ((threadIdx.x & 63u) >> 4);
+            uint32_t tri = own < n_queued ? ca.slow_queue[(uint64_t)fi * ca.slow_cap + own] : 0u;
             if (tri >= n_tris) tri = n_tris - 1u;
-            cover_triangle<true>(tri_rec, ca, fc_s, bits, L, fi, tri, true);
+            cover_triangle<true>(tri_rec, ca, fc_s, bits, L, fi, tri, own < n_queued);
         }
     } else {
         // a lane per triangle (no lane leaves before the wave has put its marks together; a lane without a triangle computes
@@ -406,19 +412,23 @@ int cover_geometry(int width, int height, int n_frames, uint32_t n_tris, CoverAr
     ca.slow_cap = cap;
     return 0;
 }
-uint64_t cover_words(const CoverArgs& ca) { return cover_zero_words(ca) + (uint64_t)ca.n_frames * ca.slow_cap; }
+static_assert(sizeof(FrameConsts) == 64, "16 words per frame in the cover's allocation");
+uint64_t cover_words(const CoverArgs& ca) { return cover_zero_words(ca) + (uint64_t)ca.n_frames * ca.slow_cap + (uint64_t)ca.n_frames * 16u + 16u; }
 uint64_t cover_zero_words(const CoverArgs& ca) { return (uint64_t)ca.n_frames * ca.frame_words + (((uint64_t)ca.n_frames + 63u) & ~63ull); }
 void cover_bind(CoverArgs& ca, uint32_t* words) {
     ca.bits = words;
     ca.slow_count = words + (uint64_t)ca.n_frames * ca.frame_words;
     ca.slow_queue = words + cover_zero_words(ca);
+    uint32_t* const behind = ca.slow_queue + (uint64_t)ca.n_frames * ca.slow_cap;
+    ca.consts = behind + ((16u - (uint32_t)((uintptr_t)behind / 4u % 16u)) % 16u);      // 64-byte aligned
 }
 
 hipError_t launch_cover(const SceneDev& sc, const CoverArgs& ca, hipStream_t s) {
     if (sc.n_tris == 0 || ca.n_frames < 1) return hipSuccess;
     const dim3 grid((sc.n_tris + 255u) / 256u, (unsigned)ca.n_frames);
+    k_cover_frames<<<((unsigned)ca.n_frames + 63u) / 64u, 64, 0, s>>>(ca);
     k_cover<false><<<grid, 256, 0, s>>>(sc.tri_rec, sc.n_tris, ca);
-    const uint32_t slow_blocks = (ca.slow_cap + 3u) / 4u;      // a wave per queue entry, at most 2048 workgroups striding over the queue
+    const uint32_t slow_blocks = (ca.slow_cap + 15u) / 16u;      // sixteen lanes per queue entry, at most 2048 workgroups striding over the queue
     const dim3 grid_slow(slow_blocks < 2048u ? slow_blocks : 2048u, (unsigned)ca.n_frames);
     k_cover<true><<<grid_slow, 256, 0, s>>>(sc.tri_rec, sc.n_tris, ca);
     const uint32_t n_words = ca.tiles_y * ca.words_x;

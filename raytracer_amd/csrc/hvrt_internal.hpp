@@ -237,6 +237,7 @@ struct CoverArgs {
     uint32_t* slow_count;              // n_frames words, ZERO on entry: triangles queued for the general case, per frame
     uint32_t* slow_queue;              // n_frames x slow_cap triangle indices
     uint32_t slow_cap;
+    void* consts;                      // n_frames x 64 bytes: what k_cover_frames works out of the camera frames
 };
 // fills in the geometry fields (everything but frames / frame0 / the pointers); nonzero: the frame is too large for a pyramid
 int cover_geometry(int width, int height, int n_frames, uint32_t n_tris, CoverArgs& ca);
