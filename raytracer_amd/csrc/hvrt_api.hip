@@ -122,6 +122,7 @@ struct hvrt_ctx {
     bool tile_cover = true;
     uint32_t* cover_bits = nullptr; uint64_t cover_capacity = 0;
     uint32_t* walk_queue = nullptr; uint64_t walk_queue_capacity = 0;      // the marked tiles of a launch, in queue order (launch_compact_queue)
+    uint32_t* compact_counts = nullptr; uint64_t compact_counts_capacity = 0;      // marked tiles per 256 slots of the order (launch_compact_queue)
     CoverArgs cover_last = {};     // the last launch that ran the pre-pass (n_frames == 0: none since the scene changed)
     // ... and its cameras: a launch with the same cameras, frame size and mesh finds its cover standing (HVRT_TILE_COVER_CACHE=0:
     // every launch runs the pre-pass)
@@ -578,7 +579,7 @@ void hvrt_destroy(hvrt_ctx* c) {
     if (c->df_stream) (void)hipStreamSynchronize(c->df_stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     void* bufs[] = { c->tri_aos, c->tri_rec, c->cnt_base, c->indices, c->ref_rec, c->face_bits, c->dist, c->ranges, c->sat_mask, c->cnt16, c->occ_bits, c->stats, c->long_queue, c->fill_scratch,
-                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned, c->cover_bits, c->walk_queue, c->sample_rgb, c->sample_done,
+                     c->bounds_v, c->bounds_i, c->bounds_out, c->tile_counter, c->counters, c->cost_sum, c->order_blocks, c->cam_dev, c->tile_cost, c->tile_order, c->split_tiles, c->abandoned, c->cover_bits, c->walk_queue, c->compact_counts, c->sample_rgb, c->sample_done,
                      c->out_buf[0], c->out_buf[1], c->out_buf[2], c->io_buf[0], c->io_buf[1], c->io_buf[2] };
     for (void* b : bufs) if (b) (void)hipFree(b);
     c->ev[6] = c->ev[7] = nullptr;          // aliases of ring entries
@@ -1164,7 +1165,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     if (int r = ensure<uint32_t>(c, c->tile_order, c->tile_order_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->split_tiles, c->split_tiles_capacity, n_tiles)) return r;
     if (int r = ensure<uint32_t>(c, c->abandoned, c->abandoned_capacity, n_tiles)) return r;
-    if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, 3 * (order_blocks + 1))) return r;
+    if (int r = ensure<uint32_t>(c, c->order_blocks, c->order_blocks_capacity, (uint64_t)ORDER_ARRAYS * (order_blocks + 1))) return r;
     // ... and of a view near this one: a queue ordered by the durations of a view a few degrees away is worse than an
     // unordered one (config 2, an orbit in steps of 2 / 3 / 5 / 7 degrees: 1.55 / 1.71 / 1.89 / 2.09 ms per frame with the
     // previous frame's durations, 1.69-1.75 with none; scripts/time_moving.py), so past 2.5 degrees this is a first launch
@@ -1203,11 +1204,13 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     CoverArgs ca;
     const bool use_cover = c->tile_cover && !d_counters && n_tiles != 0 && scene_of(c).n_tris != 0 &&
                            cover_geometry(width, height, n_frames, scene_of(c).n_tris, ca) == 0;
-    bool cover_stands = false, fill_beside = false;
+    bool cover_stands = false, fill_beside = false, split_behind_cover = false;
+    RenderArgs ra_fill;
     if (use_cover) {
         const uint32_t* const before = c->cover_bits;
         if (int r = ensure<uint32_t>(c, c->cover_bits, c->cover_capacity, cover_words(ca))) return r;
         if (int r = ensure<uint32_t>(c, c->walk_queue, c->walk_queue_capacity, n_tiles)) return r;
+        if (int r = ensure<uint32_t>(c, c->compact_counts, c->compact_counts_capacity, order_blocks)) return r;
         const CoverArgs& l = c->cover_last;
         cover_stands = c->cover_cache && before == c->cover_bits && l.n_frames == n_frames && l.width == width && l.height == height &&
                        memcmp(c->cover_frames, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames) == 0;
@@ -1230,21 +1233,33 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         // slot ranges are cut from the full order: there k_render passes the unmarked tiles by as it meets them.
         const bool in_segments = reuse && plan && plan->n > 1 && plan->n <= 8 && n_frames == 1;
         uint32_t* const counters = c->tile_counter + 50;      // two words of the queue scratch, zero like the queue's heads
-        // (the fill writes other pixels than the traversal: it runs beside it, on the stream builds use for the distance field)
-        HIP_TRY(c, hipEventRecord(c->ev_fill_fork, s));
-        HIP_TRY(c, hipStreamWaitEvent(c->df_stream, c->ev_fill_fork, 0));
-        HIP_TRY(c, launch_fill_background(ra, c->df_stream));
-        HIP_TRY(c, hipEventRecord(c->ev_fill_join, c->df_stream));
-        fill_beside = true;
+        const RenderArgs ra_fill_now = ra;
         if (!in_segments) {
-            if (!c->queue_clean) HIP_TRY(c, hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), s));
-            HIP_TRY(c, launch_compact_queue(ra, ra.order, reuse ? ra.n_front : nullptr, c->walk_queue, counters, s));
+            HIP_TRY(c, launch_compact_queue(ra, ra.order, reuse ? ra.n_front : nullptr, c->compact_counts, c->walk_queue, counters, s));
             ra.order = c->walk_queue; ra.n_queue = counters; ra.n_front = reuse ? counters + 1 : nullptr;
             ra.cover = nullptr;
         }
+        // (the fill writes other pixels than the traversal: it runs beside it, on the stream builds use for the distance field.
+        // It and k_render_split start here, behind the cover pass and the queue's two small kernels, which the traversal waits
+        // for: beside those, the two took the wave slots -- the cover pass of an orbit's frame then lasted 290 us instead of
+        // 120, the queue's kernels 100 instead of 12)
+        ra_fill = ra_fill_now;
+        fill_beside = true;
+        split_behind_cover = true;
+        HIP_TRY(c, hipEventRecord(c->ev_split_fork, s));
     } else {
         c->cover_last.n_frames = 0;
     }
+    // (the fill, on its own stream, from the point where this is called: behind k_wait_split_started, or that kernel waits
+    // out its 100 us for workgroups that find the fill's waves in their places)
+    auto start_fill = [&]() -> int {
+        if (!fill_beside) return 0;
+        HIP_TRY(c, hipEventRecord(c->ev_fill_fork, s));
+        HIP_TRY(c, hipStreamWaitEvent(c->df_stream, c->ev_fill_fork, 0));
+        HIP_TRY(c, launch_fill_background(ra_fill, c->n_cus, c->df_stream));
+        HIP_TRY(c, hipEventRecord(c->ev_fill_join, c->df_stream));
+        return 0;
+    };
     const bool queued_behind_ev6 = !c->queue_clean;
     if (!c->queue_clean) {
         HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // [0] a single head, [1] abandoned count, [8..15] the heads of segment launches
@@ -1275,7 +1290,8 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             // the tiles too long for one wave go first and beside the others, on the second stream
             // (the fork is the launch's own first timing event when nothing was queued behind it: one packet fewer in the stream)
             hipEvent_t fork = c->ev[6];
-            if (queued_behind_ev6) { fork = c->ev_split_fork; HIP_TRY(c, hipEventRecord(fork, s)); }
+            if (split_behind_cover) fork = c->ev_split_fork;
+            else if (queued_behind_ev6) { fork = c->ev_split_fork; HIP_TRY(c, hipEventRecord(fork, s)); }
             HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, fork, 0));
             RenderArgs rsplit = ra;
             rsplit.split_started = c->wait_for_split ? c->tile_counter + 48 : nullptr;      // a word of the 64-word scratch, never reset
@@ -1293,6 +1309,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
                 HIP_TRY(c, launch_wait_split_started(rsplit.split_started, c->split_started_total, 100u, s));
             }
         }
+        if (int r = start_fill()) return r;
         if (plan && plan->n > 1 && plan->n <= 8 && n_frames == 1) {
             // several launches over consecutive row ranges of this one queue; the long tiles (the queue's head) and the
             // tiles of k_render_split belong to the first
@@ -1317,6 +1334,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         // no history: the kernel may give up on over-long tiles; k_render_split renders those behind it (none,
         // as a rule: it then finds an empty list and ends)
         const bool abortable = c->adaptive_split && n_tiles != 0 && c->abort_ticks > 0;    // HVRT_TILE_ABORT_US=0: never give up
+        if (int r = start_fill()) return r;
         HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, abortable, s));
         if (abortable) {
             RenderArgs rb = ra;

@@ -183,6 +183,8 @@ hipError_t launch_bounds(const float* pts, uint64_t n_points, float* partial /* 
                          uint64_t* partial_idx, int n_blocks, float* out6, hipStream_t s);
 int bounds_blocks(uint64_t n_points);
 
+constexpr int ORDER_BINS = 6;                    // long classes of the tile order (launch_order_build)
+constexpr int ORDER_ARRAYS = ORDER_BINS + 2;     // count arrays: split, the long classes, the other walked tiles
 // ---- launchers (hvrt_trace.hip) ----
 // a full-size dispatch of a kernel with 160 bytes of scratch per lane (a queue's scratch set-up), nothing else
 hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s);
@@ -190,12 +192,12 @@ hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s);
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
 // with ra.cover: the pixels of the tiles the cover does not mark (k_render passes those by); in front of launch_render
-hipError_t launch_fill_background(const RenderArgs& ra, hipStream_t s);
+hipError_t launch_fill_background(const RenderArgs& ra, int n_cus, hipStream_t s);
 // with ra.cover: queue <- the marked tiles of order_in (null: of the natural order) in nearly that order; counters[0] <- how
 // many, counters[1] <- how many of them from order_in's first *n_front_in slots (both zero on entry); unmarked tiles get a
 // duration of zero.  A launch_render over that queue (order = queue, n_queue = counters, n_front = counters + 1) needs no cover.
-hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* queue,
-                                uint32_t* counters, hipStream_t s);
+hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* block_marked,
+                                uint32_t* queue, uint32_t* counters, hipStream_t s);
 hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups = nullptr,
                                uint32_t expected_tiles = 0);
 // One wave that waits (at most timeout_us) until *started has reached `target` (wrap-around compare): queued in front of
@@ -203,7 +205,7 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
 // before k_render's persistent waves take every slot there is.
 hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_t timeout_us, hipStream_t s);
 // split_tiles <- the tiles for k_render_split; order <- the others: long tiles (cost > 2.5 x mean) first, the
-// rest behind them in natural order.  block_count: 3 x (ceil(n_tiles / 256) + 1) u32 of scratch; afterwards
+// rest behind them in natural order.  block_count: ORDER_ARRAYS x (ceil(n_tiles / 256) + 1) u32 of scratch; afterwards
 // block_count[ceil(n_tiles / 256)] is the number of split tiles (0 when may_split is false).  *wants_split
 // (device-visible host memory) <- the number of tiles that qualify for splitting, whatever may_split says.
 hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsigned long long* cost_sum, int n_cus,

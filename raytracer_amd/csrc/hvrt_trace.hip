@@ -991,12 +991,9 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
 }
 // render_pixel for a pixel none of whose samples can hit anything (RenderArgs::cover): what it leaves for samples that all
 // miss -- the background of every sample's own v, accumulated and averaged in the same order -- without rays or walks
-__device__ __forceinline__ void background_pixel(const RenderArgs& ra, uint32_t tx, uint32_t ty, PixelResult& out) {
+__device__ __forceinline__ V3 background_colour(const RenderArgs& ra, int x, int y) {
     V3 acc = { 0.0f, 0.0f, 0.0f };
-    out.hit = HVRT_MISS; out.t = FLT_MAX; out.nv = 0; out.nt = 0;
     for (int s = 0; s < ra.spp; ++s) {
-        int x, lr_unused, y;
-        pixel_coords(ra, tx, ty, -1, x, lr_unused, y);
         float jx = 0.0f, jy = 0.0f;
         if (ra.spp > 1) jitter((uint32_t)x, (uint32_t)y, (uint32_t)s, ra.seed, jx, jy);
         const float v = ((float)y + jy) / ra.height_f;
@@ -1004,7 +1001,13 @@ __device__ __forceinline__ void background_pixel(const RenderArgs& ra, uint32_t 
         if (ra.spp == 1) acc = c; else acc = add(acc, c);
     }
     if (ra.spp > 1) { const float n = ra.spp_f; acc = { acc.x / n, acc.y / n, acc.z / n }; }
-    out.rgb = acc;
+    return acc;
+}
+__device__ __forceinline__ void background_pixel(const RenderArgs& ra, uint32_t tx, uint32_t ty, PixelResult& out) {
+    out.hit = HVRT_MISS; out.t = FLT_MAX; out.nv = 0; out.nt = 0;
+    int x, lr_unused, y;
+    pixel_coords(ra, tx, ty, -1, x, lr_unused, y);
+    out.rgb = background_colour(ra, x, y);
 }
 __device__ __forceinline__ void store_pixel(const RenderArgs& ra, uint32_t frame, int local_row, int x, const PixelResult& px) {
     const size_t p = ((size_t)frame * ra.slab_rows + local_row) * ra.width + x;
@@ -1037,23 +1040,34 @@ __device__ __forceinline__ bool tile_covered(const RenderArgs& ra, uint32_t fi, 
     return any;
 }
 
-// The pixels of the tiles the cover does not mark: the reference's result for a miss (one wave per tile; k_render finds those
-// tiles not marked and passes them by).
+// The pixels of the tiles the cover does not mark: the reference's result for a miss.  A wave takes eight tiles side by side
+// and writes them row by row -- 64 neighbouring pixels per store, where a wave per tile wrote eight pieces of 96 bytes (config
+// 2: 146 us beside the traversal, and 32 400 workgroups in the way of everything else that wanted a wave slot) -- and the
+// grid strides over the frame.
 __global__ __launch_bounds__(256) void k_fill_background(RenderArgs ra) {
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
-    const uint32_t tiles_frame = tiles_x * tiles_y;
-    const uint32_t n_tiles = tiles_frame * (uint32_t)ra.n_frames;
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (tile >= n_tiles) return;
-    const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
-    const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
-    if (tile_covered(ra, fi, tx, ty)) return;
-    int x, lr, y;
-    pixel_coords(ra, tx, ty, (int)(threadIdx.x & 63u), x, lr, y);
-    PixelResult px;
-    background_pixel(ra, tx, ty, px);
-    if (x < ra.width && lr < ra.local_rows && y < ra.height) store_pixel(ra, fi, lr, x, px);
+    const uint32_t groups_x = (tiles_x + 7u) >> 3;
+    const uint32_t units_frame = groups_x * tiles_y;
+    const uint32_t n_units = units_frame * (uint32_t)ra.n_frames;
+    const int lane = (int)(threadIdx.x & 63u);
+    for (uint32_t unit = blockIdx.x * 4u + (threadIdx.x >> 6); unit < n_units; unit += gridDim.x * 4u) {
+        const uint32_t fi = unit / units_frame, uf = unit - fi * units_frame;
+        const uint32_t ty = uf / groups_x, gx = uf - ty * groups_x;
+        const int x = (int)(gx * 64u) + lane;
+        if (x >= ra.width) continue;
+        if (tile_covered(ra, fi, (uint32_t)x >> 3, ty)) continue;
+        for (int r = 0; r < 8; ++r) {
+            const int lr = (int)(ty * 8u) + r;
+            if (lr >= ra.local_rows) break;
+            const int y = frame_row(ra, lr);
+            if (y >= ra.height) continue;
+            PixelResult px;
+            px.hit = HVRT_MISS; px.t = FLT_MAX; px.nv = 0; px.nt = 0;
+            px.rgb = background_colour(ra, x, y);
+            store_pixel(ra, fi, lr, x, px);
+        }
+    }
 }
 
 // Natural order of a launch without history: rows of tiles from the middle of the frame outwards.  The reference's cameras
@@ -1070,43 +1084,67 @@ __device__ __forceinline__ uint32_t natural_tile(uint32_t sl, uint32_t tiles_x, 
 }
 
 // With a tile cover: k_render's queue is the marked tiles only, in the order they have in order_in (null: the natural order)
-// -- nearly: every wave appends its marked tiles with one atomic, so runs of 64 slots may change places.  counters[0] <- the
-// queue's length, counters[1] <- how many of its tiles come from order_in's first *n_front_in slots (zero on entry);
-// the tiles that are not marked get a duration of zero.
-__global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ n_front_in,
-                                                      uint32_t* __restrict__ queue, uint32_t* __restrict__ counters) {
-    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
-    const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+// -- exactly: the long tiles at the head of order_in stay at the head, so that they start with the launch.  (One atomic per
+// wave for a place in the queue was simpler and let any wave's tiles land anywhere: the longest tiles of config 2 started
+// 170 us into a 450 us launch.)  Two kernels without a wait: k_compact_count leaves every workgroup's number of marked
+// tiles, k_compact_queue adds up the numbers before its own and places.  counters[0] <- the queue's length, counters[1] <-
+// how many of its tiles come from order_in's first *n_front_in slots; the tiles that are not marked get a duration of zero.
+__device__ __forceinline__ bool compact_slot(const RenderArgs& ra, const uint32_t* __restrict__ order_in, uint32_t slot, uint32_t n_in,
+                                             uint32_t tiles_x, uint32_t tiles_y, uint32_t& tile, bool clear_cost) {
     const uint32_t tiles_frame = tiles_x * tiles_y;
     const uint32_t n_tiles = tiles_frame * (uint32_t)ra.n_frames;
+    tile = 0u;
+    if (slot >= n_in) return false;
+    tile = order_in ? order_in[slot] : natural_tile(slot, tiles_x, tiles_y);
+    if (tile >= n_tiles) return false;
+    const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
+    const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
+    const bool walk = tile_covered(ra, fi, tx, ty);
+    if (clear_cost && !walk && !ra.debug_start) ra.tile_cost[tile] = 0u;
+    return walk;
+}
+__global__ __launch_bounds__(256) void k_compact_count(RenderArgs ra, const uint32_t* __restrict__ order_in, uint32_t* __restrict__ block_marked) {
+    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
+    const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+    const uint32_t n_tiles = tiles_x * tiles_y * (uint32_t)ra.n_frames;
+    const uint32_t n_in = order_in ? n_tiles - *ra.n_split : n_tiles;
+    uint32_t tile;
+    const bool walk = compact_slot(ra, order_in, blockIdx.x * 256u + threadIdx.x, n_in, tiles_x, tiles_y, tile, true);
+    __shared__ uint32_t w[4];
+    const unsigned long long m = __ballot(walk);
+    if ((threadIdx.x & 63u) == 0u) w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) block_marked[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+}
+__global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ n_front_in,
+                                                      const uint32_t* __restrict__ block_marked, uint32_t* __restrict__ queue, uint32_t* __restrict__ counters) {
+    const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
+    const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
+    const uint32_t n_tiles = tiles_x * tiles_y * (uint32_t)ra.n_frames;
     const uint32_t n_in = order_in ? n_tiles - *ra.n_split : n_tiles;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    bool walk = false;
-    uint32_t tile = 0u;
-    if (slot < n_in) {
-        tile = order_in ? order_in[slot] : natural_tile(slot, tiles_x, tiles_y);
-        if (tile < n_tiles) {
-            const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
-            const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
-            walk = tile_covered(ra, fi, tx, ty);
-            if (!walk && !ra.debug_start) ra.tile_cost[tile] = 0u;
-        }
+    uint32_t tile;
+    const bool walk = compact_slot(ra, order_in, slot, n_in, tiles_x, tiles_y, tile, false);
+    // the marked tiles of the workgroups before this one
+    uint32_t before = 0u;
+    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256u) before += block_marked[i];
+    before = (uint32_t)wave_sum64(before);      // (lane 0 holds the sum)
+    __shared__ uint32_t w[4], wb[4];
+    const unsigned long long m = __ballot(walk);
+    const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
+    if (lane == 0) { w[wv] = (uint32_t)__popcll(m); wb[wv] = before; }
+    __syncthreads();
+    uint32_t base = wb[0] + wb[1] + wb[2] + wb[3];
+    for (int k = 0; k < wv; ++k) base += w[k];
+    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));      // this slot's place, marked or not: the marked ones before it
+    if (walk) queue[at] = tile;
+    const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
+    if (slot == nf) counters[1] = at;                                   // (slot n_tiles - 1 at most holds a tile: nf = n_in below)
+    if (slot + 1u == gridDim.x * 256u) {
+        const uint32_t total = at + (walk ? 1u : 0u);
+        counters[0] = total;
+        if (nf >= gridDim.x * 256u) counters[1] = total;
     }
-    const unsigned long long m = any_lane(walk);
-    if (m == 0ull) return;
-    const int lane = (int)(threadIdx.x & 63u), first = __builtin_ctzll(m);
-    uint32_t base = 0u;
-    if (lane == first) {
-        base = atomicAdd(counters, (uint32_t)__builtin_popcountll(m));
-        const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
-        const uint32_t slot0 = slot - (uint32_t)lane;      // the wave's first slot
-        if (slot0 < nf) {
-            const uint32_t in_front = nf - slot0 >= 64u ? 64u : nf - slot0;
-            atomicAdd(counters + 1, (uint32_t)__builtin_popcountll(in_front >= 64u ? m : (m & ((1ull << in_front) - 1ull))));
-        }
-    }
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-    if (walk) queue[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = tile;
 }
 
 // Persistent threads: every wave loops pulling 8x8 pixel tiles until the queue is empty; the
@@ -1119,6 +1157,9 @@ __global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint
 // vector registers across the walk (render_pixel); the counting variants keep 24-40 bytes per lane there.
 #ifndef HVRT_RENDER_WAVES
 #define HVRT_RENDER_WAVES 8
+#endif
+#ifndef HVRT_SPLIT_WAVES
+#define HVRT_SPLIT_WAVES 6           // k_render_split: 80 vector registers instead of 84 (88 allocated) -- four of its waves and three of k_render's share a SIMD's 512
 #endif
 #ifndef HVRT_RENDER_BLOCK
 #define HVRT_RENDER_BLOCK 256          // lanes per workgroup of k_render / k_render_segment
@@ -1513,7 +1554,7 @@ __global__ __launch_bounds__(HVRT_RENDER_BLOCK) __attribute__((amdgpu_waves_per_
 // of each list (trace_ray, RAYS = 4).  It runs beside k_render on a second stream.  Items are dealt round-robin
 // with a bounded loop (no queue): they are few and of one kind.
 template <bool COUNT, bool INLINE, bool NEAREST>
-__global__ __launch_bounds__(256) void k_render_split(SceneDev sc, RenderArgs ra) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_SPLIT_WAVES, HVRT_SPLIT_WAVES))) void k_render_split(SceneDev sc, RenderArgs ra) {
     const int lane = threadIdx.x & 63;
     const int ray = lane & 3, slice = lane >> 2;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
@@ -1581,38 +1622,61 @@ __device__ __forceinline__ uint32_t walked_tiles(const unsigned long long* __res
     const unsigned long long w = sum[2];
     return w == 0ull || w > (unsigned long long)n ? n : (uint32_t)w;
 }
-// (slots_f: the wave slots in the low 20 bits, ten times the second rule's factor above them)
-constexpr uint32_t SPLIT_MEAN_X10 = 15u;      // config 2 with a tile cover, factor 1 / 1.5 / 2 / 3 / 4 / 6: 1.22 / 0.76 / 0.85 / 1.02 / 1.14 / 1.31 ms
-__device__ __forceinline__ bool tile_wants_split(uint32_t c, unsigned long long sum, uint32_t slots_f, uint32_t walked) {
-    const uint32_t slots = slots_f & 0xFFFFFu, f10 = slots_f >> 20;
+// What the order build goes by: the wave slots k_render keeps resident, ten times the second split rule's factor, and the
+// lower bounds of the long classes in hundredths of the mean walked tile, highest first.
+// (ten times the factor; with the queue in class order, configs 2 / 3 / 4 at 1.2 / 1.5 / 1.8 / 2.0 / 2.2 / 2.5:
+// 0.91 / 0.55 / 0.52 / 0.52 / 0.53 / 0.52, 0.96 / 0.91 / 0.90 / 0.92 / 0.94 / 1.00 and - / - / 9.9 / 9.6 / 9.5 / 9.4 ms: flat from 1.8 to 2.2)
+#ifndef HVRT_SPLIT_X10
+#define HVRT_SPLIT_X10 20
+#endif
+#ifndef HVRT_ORDER_CLASSES
+#define HVRT_ORDER_CLASSES ORDER_BINS      // long classes in use (1: the tiles above the first bound only)
+#endif
+constexpr uint32_t SPLIT_MEAN_X10 = HVRT_SPLIT_X10;
+struct OrderRule { uint32_t slots, split_x10, bin_x100[ORDER_BINS]; };
+__device__ __forceinline__ bool tile_wants_split(uint32_t c, unsigned long long sum, const OrderRule& r, uint32_t walked) {
     // longer than the balanced launch, and (where the walked tiles are hardly more than the wave slots, so that nearly
-    // every one of them is "longer than the balanced launch") longer than one and a half mean walked tiles
-    return (c & COST_SPLIT_FLAG) || ((unsigned long long)c * slots > sum && (unsigned long long)c * walked * 10ull > (unsigned long long)f10 * sum);
+    // every one of them is "longer than the balanced launch") longer than split_x10 / 10 mean walked tiles
+    return (c & COST_SPLIT_FLAG) || ((unsigned long long)c * r.slots > sum && (unsigned long long)c * walked * 10ull > (unsigned long long)r.split_x10 * sum);
 }
-// Classes: 3 split, 2 long (more than 2.5 mean WALKED tiles), 1 walked (more than 2.5 x the mean over ALL n tiles: with a
-// tile cover, where most tiles cost next to nothing, that is every walked tile -- they go in front of the cheap ones, and
-// the waves then size their pulls for each kind on its own), 0 the rest.  Without a cover walked == n and class 1 is empty.
-__device__ __forceinline__ int tile_class(uint32_t c, unsigned long long sum, uint32_t n, uint32_t walked, uint32_t slots, bool may_split) {
-    if (may_split && tile_wants_split(c, sum, slots, walked)) return 3;
-    const unsigned long long c2 = (unsigned long long)(c & ~COST_SPLIT_FLAG) * 2ull;
-    return c2 * walked > 5ull * sum ? 2 : (c2 * n > 5ull * sum ? 1 : 0);
+// Classes, in the order of the queue: ORDER_BINS long classes (the longest tiles first: what starts with the launch is
+// resident from its first microsecond, what comes later waits for a wave slot -- a launch with a tile cover ends with the
+// tile that was both long and late), then the other walked tiles (more than 2.5 x the mean over ALL n tiles: with a tile
+// cover, where most tiles cost next to nothing, that is every walked tile; without one walked == n and the class is
+// empty), then the rest; each class in natural order -- neighbours in the queue stay neighbours in the image.
+// Returns the index of the class's count array: 0 split, 1 .. ORDER_BINS the long classes, ORDER_BINS + 1 walked; -1 the rest.
+__device__ __forceinline__ int tile_class(uint32_t c, unsigned long long sum, uint32_t n, uint32_t walked, const OrderRule& r, bool may_split) {
+    if (may_split && tile_wants_split(c, sum, r, walked)) return 0;
+    const unsigned long long cw = (unsigned long long)(c & ~COST_SPLIT_FLAG);
+    // (most tiles walked -- no tile cover: one long class, more than 2.5 mean tiles, about 0.5 % of a frame; the others stay
+    // where they lie: a queue in cost order loses the caches what it gains in balance -- config 3 without a cover 2.50 ms
+    // with the one class, 2.93 with all of them)
+    if ((unsigned long long)walked * 2ull > (unsigned long long)n) return cw * 2ull * walked > 5ull * sum ? 1 : -1;
+#pragma unroll
+    for (int j = 0; j < HVRT_ORDER_CLASSES; ++j)
+        if (cw * walked * 100ull > (unsigned long long)r.bin_x100[j] * sum) return 1 + j;
+    return cw * 2ull * n > 5ull * sum ? ORDER_BINS + 1 : -1;
 }
-// block_count: three arrays of n_blocks + 1 words: tiles per block that qualify for splitting (allowed or not), long tiles
-// per block, walked tiles per block
+// block_count: ORDER_ARRAYS arrays of n_blocks + 1 words: per block of 256 tiles, the tiles that qualify for splitting
+// (allowed or not), the tiles of each long class, the other walked tiles
 __global__ __launch_bounds__(256) void k_order_count(const uint32_t* __restrict__ cost, uint32_t n,
-                                                     const unsigned long long* __restrict__ sum, uint32_t slots,
+                                                     const unsigned long long* __restrict__ sum, OrderRule rule,
                                                      bool may_split, uint32_t* __restrict__ block_count) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     const uint32_t walked = walked_tiles(sum, n);
-    const bool wants = i < n && tile_wants_split(cost[i], *sum, slots, walked);
-    const int cls = i < n ? tile_class(cost[i], *sum, n, walked, slots, may_split) : 0;
-    __shared__ uint32_t w[3][4];
-    const unsigned long long m3 = __ballot(wants), m2 = __ballot(cls == 2), m1 = __ballot(cls == 1);
-    if ((threadIdx.x & 63) == 0) { w[0][threadIdx.x >> 6] = (uint32_t)__popcll(m3); w[1][threadIdx.x >> 6] = (uint32_t)__popcll(m2); w[2][threadIdx.x >> 6] = (uint32_t)__popcll(m1); }
+    const bool wants = i < n && tile_wants_split(cost[i], *sum, rule, walked);
+    const int cls = i < n ? tile_class(cost[i], *sum, n, walked, rule, may_split) : -1;
+    __shared__ uint32_t w[ORDER_ARRAYS][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < ORDER_ARRAYS; ++a) {
+        const unsigned long long m = __ballot(a == 0 ? wants : cls == a);
+        if (lane == 0) w[a][wv] = (uint32_t)__popcll(m);
+    }
     __syncthreads();
-    if (threadIdx.x < 3) block_count[threadIdx.x * (gridDim.x + 1) + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
+    if (threadIdx.x < ORDER_ARRAYS) block_count[threadIdx.x * (gridDim.x + 1) + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
 }
-// each of the three count arrays <- its exclusive scan, [n_blocks] <- its total (one workgroup per array).  The
+// each of the count arrays <- its exclusive scan, [n_blocks] <- its total (one workgroup per array).  The
 // number of tiles that qualify for splitting goes to *wants_split (pinned host memory, one store; the host reads
 // it, without waiting, to decide whether the NEXT launch gets a k_render_split); when this launch may not split,
 // the first array is cleared instead -- nothing is split.
@@ -1645,39 +1709,58 @@ __global__ __launch_bounds__(1024) void k_order_scan(uint32_t* __restrict__ bloc
         }
     }
 }
-// order[0, n - n_split): k_render's queue (long tiles, walked tiles, the rest; each in natural order); split_tiles[0,
-// n_split): k_render_split's tiles, whose cost words are reset to the bare flag (that kernel adds its quads' durations
-// to them)
+// (the tiles at the queue's head: the long classes and the other walked tiles)
+__device__ __forceinline__ uint32_t order_front_tiles(const uint32_t* __restrict__ block_count, uint32_t n_blocks) {
+    uint32_t f = 0;
+#pragma unroll
+    for (int a = 1; a < ORDER_ARRAYS; ++a) f += block_count[a * (n_blocks + 1) + n_blocks];
+    return f;
+}
+// order[0, n - n_split): k_render's queue (the classes above, each in natural order); split_tiles[0, n_split):
+// k_render_split's tiles, whose cost words are reset to the bare flag (that kernel adds its quads' durations to them)
 __global__ __launch_bounds__(256) void k_order_place(uint32_t* __restrict__ cost, uint32_t n,
-                                                     const unsigned long long* __restrict__ sum, uint32_t slots, bool may_split,
+                                                     const unsigned long long* __restrict__ sum, OrderRule rule, bool may_split,
                                                      const uint32_t* __restrict__ block_count, uint32_t n_blocks,
                                                      uint32_t* __restrict__ order, uint32_t* __restrict__ split_tiles,
                                                      uint32_t* __restrict__ clear_heads, unsigned long long* __restrict__ clear_sum) {
     // (clear_heads[49], never cleared: the number of long and walked tiles at the queue's head, RenderArgs::n_front)
-    if (blockIdx.x == 0 && threadIdx.x == 26 && clear_heads) clear_heads[49] = block_count[2 * n_blocks + 1] + block_count[3 * n_blocks + 2];
-    if (blockIdx.x == 0 && (threadIdx.x == 27 || threadIdx.x == 28) && clear_heads) clear_heads[50 + (threadIdx.x - 27)] = 0u;      // k_compact_queue's counters
+    if (blockIdx.x == 0 && threadIdx.x == 26 && clear_heads) clear_heads[49] = order_front_tiles(block_count, n_blocks);
+    if (blockIdx.x == 0 && (threadIdx.x == 27 || threadIdx.x == 28) && clear_heads) clear_heads[50 + (threadIdx.x - 27)] = 0u;      // launch_compact_queue's counters
     // (nullable: the 24 queue-head words and the cost sum the NEXT launch starts from -- not the sum read here)
     if (blockIdx.x == 0 && threadIdx.x < 16 && clear_heads) clear_heads[threadIdx.x] = 0u;
     if (blockIdx.x == 0 && threadIdx.x >= 16 && threadIdx.x < 24 && clear_heads) clear_heads[64 + 32 * (threadIdx.x - 16)] = 0u;
     if (blockIdx.x == 0 && (threadIdx.x == 24 || threadIdx.x == 25) && clear_sum) clear_sum[2 * (threadIdx.x - 24)] = 0ull;      // the sum and its walked count
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const int cls = i < n ? tile_class(cost[i], *sum, n, walked_tiles(sum, n), slots, may_split) : 0;
-    __shared__ uint32_t w[3][4];
-    const unsigned long long m3 = __ballot(cls == 3), m2 = __ballot(cls == 2), m1 = __ballot(cls == 1);
+    const int cls = i < n ? tile_class(cost[i], *sum, n, walked_tiles(sum, n), rule, may_split) : -1;
+    __shared__ uint32_t w[ORDER_ARRAYS][4];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { w[0][wv] = (uint32_t)__popcll(m3); w[1][wv] = (uint32_t)__popcll(m2); w[2][wv] = (uint32_t)__popcll(m1); }
-    __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t before3 = block_count[blockIdx.x] + (uint32_t)__popcll(m3 & below);
-    uint32_t before2 = block_count[n_blocks + 1 + blockIdx.x] + (uint32_t)__popcll(m2 & below);
-    uint32_t before1 = block_count[2 * (n_blocks + 1) + blockIdx.x] + (uint32_t)__popcll(m1 & below);
-    for (int k = 0; k < wv; ++k) { before3 += w[0][k]; before2 += w[1][k]; before1 += w[2][k]; }
+    uint32_t mine = 0;          // tiles of my class before me in my wave
+    uint32_t classed = 0;       // tiles of any class before me in my workgroup (wave part)
+#pragma unroll
+    for (int a = 0; a < ORDER_ARRAYS; ++a) {
+        const unsigned long long m = __ballot(cls == a);
+        if (lane == 0) w[a][wv] = (uint32_t)__popcll(m);
+        if (cls == a) mine = (uint32_t)__popcll(m & below);
+        classed += (uint32_t)__popcll(m & below);
+    }
+    __syncthreads();
     if (i >= n) return;
-    const uint32_t n_long = block_count[2 * n_blocks + 1], n_walked = block_count[3 * n_blocks + 2];
-    if (cls == 3) { split_tiles[before3] = i; cost[i] = COST_SPLIT_FLAG; }
-    else if (cls == 2) order[before2] = i;
-    else if (cls == 1) order[n_long + before1] = i;
-    else order[n_long + n_walked + (i - before3 - before2 - before1)] = i;
+    if (cls >= 0) {
+        uint32_t at = block_count[cls * (n_blocks + 1) + blockIdx.x] + mine;
+        for (int k = 0; k < wv; ++k) at += w[cls][k];
+        if (cls == 0) { split_tiles[at] = i; cost[i] = COST_SPLIT_FLAG; return; }
+        for (int a = 1; a < cls; ++a) at += block_count[a * (n_blocks + 1) + n_blocks];      // the classes in front of mine
+        order[at] = i;
+    } else {
+        // the rest: my index less the classed tiles before me
+        uint32_t before = classed;
+        for (int a = 0; a < ORDER_ARRAYS; ++a) {
+            before += block_count[a * (n_blocks + 1) + blockIdx.x];
+            for (int k = 0; k < wv; ++k) before += w[a][k];
+        }
+        order[order_front_tiles(block_count, n_blocks) + (i - before)] = i;
+    }
 }
 
 // Slot ranges for a frame rendered as several launches over one queue (RenderArgs::seg_slots): behind the long tiles
@@ -1688,7 +1771,7 @@ __global__ __launch_bounds__(64) void k_order_segments(const uint32_t* __restric
                                                         uint32_t* __restrict__ seg_slots) {
     const int i = (int)threadIdx.x;
     if (i > n_seg) return;
-    const uint32_t n_split = block_count[n_blocks], n_long = block_count[2 * n_blocks + 1] + block_count[3 * n_blocks + 2];   // long and walked: the queue's head
+    const uint32_t n_split = block_count[n_blocks], n_long = order_front_tiles(block_count, n_blocks);   // long and walked: the queue's head
     const uint32_t n_queue = n_tiles - n_split;
     if (i == 0) { seg_slots[0] = 0; return; }
     if (i == n_seg) { seg_slots[i] = n_queue; return; }
@@ -1786,16 +1869,22 @@ uint64_t render_tile_count(int width, int local_rows, int n_frames) {
     return tiles_x * tiles_y * (uint64_t)n_frames;
 }
 
-hipError_t launch_fill_background(const RenderArgs& ra, hipStream_t s) {
+hipError_t launch_fill_background(const RenderArgs& ra, int n_cus, hipStream_t s) {
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.cover) return hipSuccess;
-    k_fill_background<<<(unsigned)((n_tiles + 3) / 4), 256, 0, s>>>(ra);
+    const uint64_t units = (uint64_t)((((ra.width + 7) >> 3) + 7) >> 3) * (uint64_t)((ra.local_rows + 7) >> 3) * (uint64_t)ra.n_frames;
+    uint64_t blocks = (units + 3) / 4;
+    if (blocks > (uint64_t)n_cus * 4u) blocks = (uint64_t)n_cus * 4u;      // four waves per SIMD at most
+    k_fill_background<<<(unsigned)blocks, 256, 0, s>>>(ra);
     return hipGetLastError();
 }
-hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* queue, uint32_t* counters, hipStream_t s) {
+hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* block_marked,
+                                uint32_t* queue, uint32_t* counters, hipStream_t s) {
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
-    if (n_tiles == 0 || !ra.cover) return hipErrorInvalidValue;
-    k_compact_queue<<<(unsigned)((n_tiles + 255) / 256), 256, 0, s>>>(ra, order_in, n_front_in, queue, counters);
+    if (n_tiles == 0 || !ra.cover || !block_marked) return hipErrorInvalidValue;
+    const unsigned nb = (unsigned)((n_tiles + 255) / 256);
+    k_compact_count<<<nb, 256, 0, s>>>(ra, order_in, block_marked);
+    k_compact_queue<<<nb, 256, 0, s>>>(ra, order_in, n_front_in, block_marked, queue, counters);
     return hipGetLastError();
 }
 
@@ -1844,7 +1933,9 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.order) return hipSuccess;
     uint64_t blocks = n_tiles * 4;                         // 16 waves per tile, were every tile split
-    const uint64_t cap = (uint64_t)n_cus * 4;
+    // (workgroups per CU at most: 3 / 4 / 5 / 6 with the ordered queue: config 2 0.50 / 0.52 / 0.53 / 0.53 ms, config 3
+    // 0.78 / 0.69 / 0.68 / 0.68, config 4 9.4 throughout)
+    const uint64_t cap = (uint64_t)n_cus * 6u;
     if (blocks > cap) blocks = cap;
     // (the caller's idea of how many tiles there are, when it has one: twice the workgroups they need, 16 at least --
     // the items are dealt round-robin, so a count that was too low costs time, not tiles)
@@ -1886,15 +1977,22 @@ hipError_t launch_order_build(uint32_t* tile_cost, uint32_t n_tiles, const unsig
                               bool may_split, uint32_t* block_count, uint32_t* order, uint32_t* split_tiles,
                               uint32_t* wants_split, uint32_t serial, uint32_t* clear_heads, unsigned long long* clear_sum, bool by_sample, hipStream_t s) {
     const unsigned blocks = (n_tiles + 255u) / 256u;
-    uint32_t slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
+    OrderRule rule;
+    rule.slots = (uint32_t)n_cus * 4u * (uint32_t)HVRT_RENDER_WAVES;     // the waves k_render keeps resident
     // (tiles rendered sample by sample cost no more than in one piece: the bar is lower)
     // (config 4, the bar at 1 / 2 / 4 / 8 times the slots: 11.8 / 10.6 / 11.0 / 11.1 ms)
-    if (by_sample) slots *= 2u;
-    slots |= SPLIT_MEAN_X10 << 20;
+    if (by_sample) rule.slots *= 2u;
+    rule.split_x10 = SPLIT_MEAN_X10;
+    // the long classes: from the split rule's bar down to the mean walked tile, in equal ratios (178, 158, 141, 125, 112, 100
+    // hundredths).  Configs 2 / 3 / 4 with the classes' lower end at 0.6 / 0.8 / 1.0 mean walked tiles:
+    // 0.55 / 0.53 / 0.53, 0.69 / 0.69 / 0.68 and 9.7 / 9.5 / 9.4 ms; with ONE long class (more than 2.5 mean walked
+    // tiles, none once the split rule's bar is there) 0.68 / 0.89 / 10.9
+    for (int j = 0; j < ORDER_BINS; ++j)
+        rule.bin_x100[j] = (uint32_t)(100.0 * pow((double)SPLIT_MEAN_X10 / 10.0, (double)(ORDER_BINS - 1 - j) / (double)ORDER_BINS));
     may_split = may_split && n_tiles <= 0x0FFFFFFFu;       // 16 items per tile in a 32-bit count
-    k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count);
-    k_order_scan<<<3, 1024, 0, s>>>(block_count, blocks, may_split, wants_split, serial);
-    k_order_place<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, slots, may_split, block_count, blocks, order, split_tiles, clear_heads, clear_sum);
+    k_order_count<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, rule, may_split, block_count);
+    k_order_scan<<<ORDER_ARRAYS, 1024, 0, s>>>(block_count, blocks, may_split, wants_split, serial);
+    k_order_place<<<blocks, 256, 0, s>>>(tile_cost, n_tiles, cost_sum, rule, may_split, block_count, blocks, order, split_tiles, clear_heads, clear_sum);
     return hipGetLastError();
 }
 

@@ -31,6 +31,7 @@ ctx.synchronize()
 for k in range(1, n + 1): render(cam_at(step * k))
 mov = ctx.render_history(n)
 print("moving :", " ".join(f"{v:.2f}" for v in mov), f"  mean {np.mean(mov):.3f}", flush=True)
+if os.environ.get("HVRT_MOVING_ONLY"): ctx.close(); sys.exit(0)
 still = []
 for k in range(1, n + 1, max(1, n // 5)):
     for _ in range(5): render(cam_at(step * k))

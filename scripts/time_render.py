@@ -13,6 +13,8 @@ if which == "c2":
     tris, g, W, H = meshgen.cube_sphere(289), 256, 3840, 2160
 elif which == "c3":
     tris, g, W, H = meshgen.skewed_statue(289, 2100), 512, 3840, 2160     # 1.0M base + 8.8M patch
+elif which == "c3b":
+    tris, g, W, H = meshgen.skewed_statue(913, 1100), 512, 3840, 2160     # the bench's config 3
 elif which == "c4":
     tris, g, W, H = meshgen.cube_sphere(289), 256, 7680, 4320                 # config 2 scene at 8K, 16 spp
 elif which == "small":
