@@ -140,7 +140,9 @@ __device__ __forceinline__ void mark(uint32_t* __restrict__ bits, const CoverArg
 }
 
 __device__ __forceinline__ void or_word(uint32_t* __restrict__ w, uint32_t b, const CoverArgs& ca) {
-    atomicOr(w, b);       // (no look first: the wave has already put its lanes' bits together, and nothing waits for the result)
+    // (no look first: the wave has already put its lanes' bits together, and nothing waits for the result; with a look the
+    // first pass over config 2 took 90 us instead of 62)
+    atomicOr(w, b);
 }
 // OR over the 64 lanes (all must be active): two quad swaps, the two row mirrors, then the four rows' values
 __device__ __forceinline__ uint32_t wave_or(uint32_t v) {
@@ -260,17 +262,18 @@ __device__ __forceinline__ void cover_triangle(const float4* __restrict__ tri_re
         if (!pend) break;                                               // rows only get fewer
         const uint32_t key = yy * ca.words_x + (tx_lo >> 5);         // level 0: word (tx_lo / 32) of row yy
         const uint64_t m64 = (uint64_t)((1u << (tx_hi - tx_lo + 1u)) - 1u) << (tx_lo & 31u);
+        uint32_t my_lo = 0u, my_hi = 0u;      // a leader's words: what its group marks
         while (pend) {
             const int leader = __builtin_ctzll(pend);
             const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
             const bool mine = has && key == k0;
             const uint32_t lo = wave_or(mine ? (uint32_t)m64 : 0u), hi = wave_or(mine ? (uint32_t)(m64 >> 32) : 0u);
-            if ((int)(threadIdx.x & 63u) == leader) {
-                or_word(bits + k0, lo, ca);
-                if (hi) or_word(bits + k0 + 1u, hi, ca);
-            }
+            if ((int)(threadIdx.x & 63u) == leader) { my_lo = lo; my_hi = hi; }
             pend &= ~__builtin_amdgcn_ballot_w64(mine);
         }
+        // the leaders mark, all at once
+        if (my_lo) or_word(bits + key, my_lo, ca);
+        if (my_hi) or_word(bits + key + 1u, my_hi, ca);
     }
     if (!SLOW) {
         // the general case goes to the queue, one reservation per wave; what does not fit stays here
@@ -284,7 +287,7 @@ __device__ __forceinline__ void cover_triangle(const float4* __restrict__ tri_re
             if (todo == 2 && at < ca.slow_cap) { ca.slow_queue[(uint64_t)fi * ca.slow_cap + at] = tri; todo = 0; }
         }
     }
-    if (todo != 2) return;
+    if (!SLOW && todo != 2) return;      // (the second pass's lanes stay: they put their marks together, like above)
 
     // ---- may a ray through the block of tiles [x, x + 2^k) x [y, y + 2^k) hit the triangle?
     auto block_test = [&](uint32_t x, uint32_t y, uint32_t k) -> bool {
@@ -312,14 +315,37 @@ __device__ __forceinline__ void cover_triangle(const float4* __restrict__ tri_re
     };
     // the rectangle in blocks of 2^k x 2^k tiles, k the smallest for which there are at most `room` of them
     const uint32_t room = SLOW ? 1024u : 64u;
-    uint32_t k = 0u;
-    while (((tx_hi >> k) - (tx_lo >> k) + 1u) * ((ty_hi >> k) - (ty_lo >> k) + 1u) > room) ++k;
-    const uint32_t bx0 = tx_lo >> k, by0 = ty_lo >> k, bw = (tx_hi >> k) - bx0 + 1u, n_blocks = bw * ((ty_hi >> k) - by0 + 1u);
+    uint32_t k = 0u, bx0 = 0u, by0 = 0u, bw = 1u, n_blocks = 0u;
+    if (todo == 2) {
+        while (((tx_hi >> k) - (tx_lo >> k) + 1u) * ((ty_hi >> k) - (ty_lo >> k) + 1u) > room) ++k;
+        bx0 = tx_lo >> k; by0 = ty_lo >> k; bw = (tx_hi >> k) - bx0 + 1u; n_blocks = bw * ((ty_hi >> k) - by0 + 1u);
+    }
     if (SLOW) {
-        // the sixteen lanes' triangle: lane i of them takes blocks i, i + 16, ...
-        for (uint32_t t = threadIdx.x & 15u; t < n_blocks; t += 16u) {
-            const uint32_t bx = bx0 + t % bw, by = by0 + t / bw;
-            if (block_test(bx << k, by << k, k)) mark(bits, ca, k, bx << k, by << k);
+        // the sixteen lanes' triangle: lane i of them takes blocks i, i + 16, ... -- neighbours in a row of the rectangle, so
+        // their marks fall into the same word or two, and the wave's four triangles are neighbours as well: the lanes whose
+        // bits belong to one word OR them together and one lane marks for all.  (One atomic per block that passes was 48 us
+        // for config 2's 11 000 queued triangles from the front and 100 us from 8 degrees beside it, with the same number of
+        // triangles and three times the marks: the silhouette's few hundred words took them one at a time.)
+        for (uint32_t t = threadIdx.x & 15u; __builtin_amdgcn_ballot_w64(t < n_blocks) != 0ull; t += 16u) {
+            bool pass = false;
+            uint32_t key = 0u, bit = 0u;
+            if (t < n_blocks) {
+                const uint32_t bx = bx0 + t % bw, by = by0 + t / bw;
+                pass = block_test(bx << k, by << k, k);
+                key = (k * ca.tiles_y + by) * ca.words_x + (bx >> 5);      // (mark()'s word, bx and by being block numbers of level k)
+                bit = 1u << (bx & 31u);
+            }
+            uint64_t pend = __builtin_amdgcn_ballot_w64(pass);
+            uint32_t my = 0u;
+            while (pend) {
+                const int leader = __builtin_ctzll(pend);
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+                const bool mine = pass && key == k0;
+                const uint32_t m = wave_or(mine ? bit : 0u);
+                if ((int)(threadIdx.x & 63u) == leader) my = m;
+                pend &= ~__builtin_amdgcn_ballot_w64(mine);
+            }
+            if (my) or_word(bits + key, my, ca);
         }
     } else {
         // (the queue was full: the lane's triangle, block by block)

@@ -1933,9 +1933,9 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.order) return hipSuccess;
     uint64_t blocks = n_tiles * 4;                         // 16 waves per tile, were every tile split
-    // (workgroups per CU at most: 3 / 4 / 5 / 6 with the ordered queue: config 2 0.50 / 0.52 / 0.53 / 0.53 ms, config 3
-    // 0.78 / 0.69 / 0.68 / 0.68, config 4 9.4 throughout)
-    const uint64_t cap = (uint64_t)n_cus * 6u;
+    // (workgroups per CU at most: 2 / 3 / 4 / 6: config 2 0.63 / 0.51 / 0.49 / 0.51 ms, config 3 0.97 / 0.93 / 0.87 / 0.86,
+    // config 4 8.8 throughout)
+    const uint64_t cap = (uint64_t)n_cus * 4u;
     if (blocks > cap) blocks = cap;
     // (the caller's idea of how many tiles there are, when it has one: twice the workgroups they need, 16 at least --
     // the items are dealt round-robin, so a count that was too low costs time, not tiles)
