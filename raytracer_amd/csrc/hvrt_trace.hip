@@ -1088,7 +1088,8 @@ __device__ __forceinline__ uint32_t natural_tile(uint32_t sl, uint32_t tiles_x, 
 // wave for a place in the queue was simpler and let any wave's tiles land anywhere: the longest tiles of config 2 started
 // 170 us into a 450 us launch.)  Two kernels without a wait: k_compact_count leaves every workgroup's number of marked
 // tiles, k_compact_queue adds up the numbers before its own and places.  counters[0] <- the queue's length, counters[1] <-
-// how many of its tiles come from order_in's first *n_front_in slots; the tiles that are not marked get a duration of zero.
+// how many tiles make up the queue's head (the waves pull those one at a time); the tiles that are not marked get a duration
+// of zero.
 __device__ __forceinline__ bool compact_slot(const RenderArgs& ra, const uint32_t* __restrict__ order_in, uint32_t slot, uint32_t n_in,
                                              uint32_t tiles_x, uint32_t tiles_y, uint32_t& tile, bool clear_cost) {
     const uint32_t tiles_frame = tiles_x * tiles_y;
@@ -1103,45 +1104,62 @@ __device__ __forceinline__ bool compact_slot(const RenderArgs& ra, const uint32_
     if (clear_cost && !walk && !ra.debug_start) ra.tile_cost[tile] = 0u;
     return walk;
 }
-__global__ __launch_bounds__(256) void k_compact_count(RenderArgs ra, const uint32_t* __restrict__ order_in, uint32_t* __restrict__ block_marked) {
+// (block_marked: two arrays of one word per workgroup -- its marked tiles, and those of them behind order_in's first
+// *n_front_in slots)
+__global__ __launch_bounds__(256) void k_compact_count(RenderArgs ra, const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ n_front_in,
+                                                      uint32_t* __restrict__ block_marked) {
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t n_tiles = tiles_x * tiles_y * (uint32_t)ra.n_frames;
     const uint32_t n_in = order_in ? n_tiles - *ra.n_split : n_tiles;
+    const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t tile;
-    const bool walk = compact_slot(ra, order_in, blockIdx.x * 256u + threadIdx.x, n_in, tiles_x, tiles_y, tile, true);
-    __shared__ uint32_t w[4];
-    const unsigned long long m = __ballot(walk);
-    if ((threadIdx.x & 63u) == 0u) w[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    const bool walk = compact_slot(ra, order_in, slot, n_in, tiles_x, tiles_y, tile, true);
+    __shared__ uint32_t w[2][4];
+    const unsigned long long m = __ballot(walk), mr = __ballot(walk && slot >= nf);
+    if ((threadIdx.x & 63u) == 0u) { w[0][threadIdx.x >> 6] = (uint32_t)__popcll(m); w[1][threadIdx.x >> 6] = (uint32_t)__popcll(mr); }
     __syncthreads();
-    if (threadIdx.x == 0) block_marked[blockIdx.x] = w[0] + w[1] + w[2] + w[3];
+    if (threadIdx.x < 2) block_marked[threadIdx.x * gridDim.x + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
 }
+// The queue: first the marked tiles from behind order_in's front -- tiles the launch that left the order did not walk, or
+// hardly: with a camera that moves they are the new silhouette, the longest tiles of the frame for all anyone knows, and at
+// the queue's end they were what an orbit's launches ended with (config 2: k_render 556 us with them last, the rest of
+// the queue done after 355) -- then the front's marked tiles, both in order_in's order.
 __global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ n_front_in,
                                                       const uint32_t* __restrict__ block_marked, uint32_t* __restrict__ queue, uint32_t* __restrict__ counters) {
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t n_tiles = tiles_x * tiles_y * (uint32_t)ra.n_frames;
     const uint32_t n_in = order_in ? n_tiles - *ra.n_split : n_tiles;
+    const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t tile;
     const bool walk = compact_slot(ra, order_in, slot, n_in, tiles_x, tiles_y, tile, false);
-    // the marked tiles of the workgroups before this one
-    uint32_t before = 0u;
-    for (uint32_t i = threadIdx.x; i < blockIdx.x; i += 256u) before += block_marked[i];
-    before = (uint32_t)wave_sum64(before);      // (lane 0 holds the sum)
-    __shared__ uint32_t w[4], wb[4];
-    const unsigned long long m = __ballot(walk);
+    const bool rest = slot >= nf;
+    // the marked tiles of the workgroups before this one (all of them, and those behind the front), and the latter's total
+    uint32_t before = 0u, before_rest = 0u, all_rest = 0u;
+    for (uint32_t i = threadIdx.x; i < gridDim.x; i += 256u) {
+        const uint32_t r = block_marked[gridDim.x + i];
+        all_rest += r;
+        if (i < blockIdx.x) { before += block_marked[i]; before_rest += r; }
+    }
+    before = (uint32_t)wave_sum64(before); before_rest = (uint32_t)wave_sum64(before_rest); all_rest = (uint32_t)wave_sum64(all_rest);      // (lane 0 holds the sums)
+    __shared__ uint32_t w[2][4], wb[3][4];
+    const unsigned long long m = __ballot(walk), mr = __ballot(walk && rest);
     const int lane = (int)(threadIdx.x & 63u), wv = (int)(threadIdx.x >> 6);
-    if (lane == 0) { w[wv] = (uint32_t)__popcll(m); wb[wv] = before; }
+    if (lane == 0) { w[0][wv] = (uint32_t)__popcll(m); w[1][wv] = (uint32_t)__popcll(mr); wb[0][wv] = before; wb[1][wv] = before_rest; wb[2][wv] = all_rest; }
     __syncthreads();
-    uint32_t base = wb[0] + wb[1] + wb[2] + wb[3];
-    for (int k = 0; k < wv; ++k) base += w[k];
-    const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));      // this slot's place, marked or not: the marked ones before it
-    if (walk) queue[at] = tile;
-    const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
-    if (slot == nf) counters[1] = at;                                   // (slot n_tiles - 1 at most holds a tile: nf = n_in below)
+    uint32_t b_all = wb[0][0] + wb[0][1] + wb[0][2] + wb[0][3], b_rest = wb[1][0] + wb[1][1] + wb[1][2] + wb[1][3];
+    const uint32_t t_rest = wb[2][0] + wb[2][1] + wb[2][2] + wb[2][3];
+    for (int k = 0; k < wv; ++k) { b_all += w[0][k]; b_rest += w[1][k]; }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t at_all = b_all + (uint32_t)__popcll(m & below);        // the marked slots before this one
+    const uint32_t at_rest = b_rest + (uint32_t)__popcll(mr & below);     // ... those of them behind the front
+    if (walk) queue[rest ? at_rest : t_rest + (at_all - at_rest)] = tile;
+    if (slot == nf) counters[1] = t_rest + at_all;                        // (no marked slot behind the front lies before slot nf)
     if (slot + 1u == gridDim.x * 256u) {
-        const uint32_t total = at + (walk ? 1u : 0u);
+        const uint32_t total = at_all + (walk ? 1u : 0u);
         counters[0] = total;
         if (nf >= gridDim.x * 256u) counters[1] = total;
     }
@@ -1883,7 +1901,7 @@ hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, 
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.cover || !block_marked) return hipErrorInvalidValue;
     const unsigned nb = (unsigned)((n_tiles + 255) / 256);
-    k_compact_count<<<nb, 256, 0, s>>>(ra, order_in, block_marked);
+    k_compact_count<<<nb, 256, 0, s>>>(ra, order_in, n_front_in, block_marked);
     k_compact_queue<<<nb, 256, 0, s>>>(ra, order_in, n_front_in, block_marked, queue, counters);
     return hipGetLastError();
 }

@@ -31,6 +31,10 @@ os.environ["HVRT_DEBUG_TILE_START"] = "1"
 ms2 = launch()
 os.environ["HVRT_DEBUG_TILE_START"] = "0"
 st = ctx.tile_costs(tx * ty).astype(np.int64)
+if len(sys.argv) > 2 and sys.argv[2] == "moving":
+    # the recorded launch left the order as it was: the same camera once more gives this frame's own durations under that order
+    launch()
+    dur = ctx.tile_costs(tx * ty).astype(np.int64)
 split = (dur >> 31) != 0
 d_us = (dur & 0x7FFFFFFF) * 16 / 2.4e3
 ok = ~split
