@@ -82,17 +82,26 @@ def test_kernel_trace_agrees_with_the_events():
     warm-up and timed steps (tile cover on) and the five launches with history of the HVRT_TILE_COVER=0 context behind them
     (`no_tile_cover_ms`; that context's first launch and the context without history run the give-up variant, a kernel of
     another name).  The summary's average over all of them is the mix of the two means the line measured with HIP events,
-    less what the events also bracket (k_compact_queue in front, the joins of the kernels beside it)."""
+    less what the events also bracket: with the tile cover, the queue's two kernels and the wait for k_render_split in front
+    of k_render (taken from the same summary), the gaps between those launches, and the end of k_render_split where it
+    outlasts k_render."""
     d = _load(f"{RND}_bench_c2_under_rocprof.json")
     with open(os.path.join(P, f"{RND}_bench_c2_kernel_stats.csv")) as f:
-        rows = [r for r in csv.DictReader(f) if KERNEL in r["Name"]]
+        all_rows = list(csv.DictReader(f))
+    rows = [r for r in all_rows if KERNEL in r["Name"]]
     assert len(rows) == 1
     calls, avg_ms, min_ms = int(rows[0]["Calls"]), float(rows[0]["AverageNs"]) * 1e-6, float(rows[0]["MinNs"]) * 1e-6
     n_cover, n_plain = d["steps"] + d["warmup"], 5
     assert calls == n_cover + n_plain
+    in_front = 0.0
+    for name in ("k_compact_count", "k_compact_queue", "k_wait_split_started"):
+        r = [r for r in all_rows if name + "(" in r["Name"]]
+        assert len(r) == 1, name
+        in_front += float(r[0]["AverageNs"]) * 1e-6
     ev_ms = (n_cover * d["roofline"]["kernel_ms"] + n_plain * d["no_tile_cover_ms"]) / calls
-    assert avg_ms <= ev_ms <= avg_ms * 1.12, (avg_ms, ev_ms)
-    assert min_ms <= d["roofline"]["kernel_ms"] <= min_ms * 1.25, (min_ms, d["roofline"]["kernel_ms"])
+    trace_ms = avg_ms + in_front * n_cover / calls
+    assert trace_ms <= ev_ms <= trace_ms * 1.15, (trace_ms, ev_ms)
+    assert min_ms <= d["roofline"]["kernel_ms"] <= min_ms * 1.40, (min_ms, d["roofline"]["kernel_ms"])
 
 
 @pytest.mark.parametrize("w", ["c2", "c3", "c4"])
