@@ -1236,7 +1236,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         const RenderArgs ra_fill_now = ra;
         if (!in_segments) {
             HIP_TRY(c, launch_compact_queue(ra, ra.order, reuse ? ra.n_front : nullptr, c->compact_counts, c->walk_queue, counters, s));
-            ra.order = c->walk_queue; ra.n_queue = counters; ra.n_front = reuse ? counters + 1 : nullptr;
+            ra.order = c->walk_queue; ra.n_queue = counters; ra.n_front = counters + 1;
             ra.cover = nullptr;
         }
         // (the fill writes other pixels than the traversal: it runs beside it, on the stream builds use for the distance field.

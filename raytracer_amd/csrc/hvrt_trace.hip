@@ -1090,8 +1090,11 @@ __device__ __forceinline__ uint32_t natural_tile(uint32_t sl, uint32_t tiles_x, 
 // tiles, k_compact_queue adds up the numbers before its own and places.  counters[0] <- the queue's length, counters[1] <-
 // how many tiles make up the queue's head (the waves pull those one at a time); the tiles that are not marked get a duration
 // of zero.
-__device__ __forceinline__ bool compact_slot(const RenderArgs& ra, const uint32_t* __restrict__ order_in, uint32_t slot, uint32_t n_in,
-                                             uint32_t tiles_x, uint32_t tiles_y, uint32_t& tile, bool clear_cost) {
+#ifndef HVRT_RIM_TILES
+#define HVRT_RIM_TILES 3
+#endif
+__device__ __forceinline__ bool compact_slot(const RenderArgs& ra, const uint32_t* __restrict__ order_in, uint32_t slot, uint32_t n_in, uint32_t nf,
+                                             uint32_t tiles_x, uint32_t tiles_y, uint32_t& tile, bool& head, bool clear_cost) {
     const uint32_t tiles_frame = tiles_x * tiles_y;
     const uint32_t n_tiles = tiles_frame * (uint32_t)ra.n_frames;
     tile = 0u;
@@ -1102,6 +1105,26 @@ __device__ __forceinline__ bool compact_slot(const RenderArgs& ra, const uint32_
     const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
     const bool walk = tile_covered(ra, fi, tx, ty);
     if (clear_cost && !walk && !ra.debug_start) ra.tile_cost[tile] = 0u;
+    // Which marked tiles go to the queue's head.  With an order: those behind its front (no duration known).  Without: the
+    // rim of the cover -- a tile not marked within RIM tiles of this one.  Rays that graze the mesh cross the most occupied
+    // voxels, so a launch without history finds its longest tiles a little inside the outline of what the cover marks,
+    // and they had better start with the launch.
+    head = false;
+    if (walk) {
+        if (order_in) head = slot >= nf;
+        else {
+            constexpr int RIM = HVRT_RIM_TILES;
+            for (int dy = -RIM; dy <= RIM && !head; ++dy) {
+                const int y = (int)ty + dy;
+                if (y < 0 || y >= (int)tiles_y) continue;
+                for (int dx = -RIM; dx <= RIM; dx += RIM) {      // (the square's corners and edge midpoints: enough for an outline that is a curve)
+                    const int x = (int)tx + dx;
+                    if (x < 0 || x >= (int)tiles_x) continue;
+                    if (!tile_covered(ra, fi, (uint32_t)x, (uint32_t)y)) { head = true; break; }
+                }
+            }
+        }
+    }
     return walk;
 }
 // (block_marked: two arrays of one word per workgroup -- its marked tiles, and those of them behind order_in's first
@@ -1115,9 +1138,10 @@ __global__ __launch_bounds__(256) void k_compact_count(RenderArgs ra, const uint
     const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t tile;
-    const bool walk = compact_slot(ra, order_in, slot, n_in, tiles_x, tiles_y, tile, true);
+    bool head;
+    const bool walk = compact_slot(ra, order_in, slot, n_in, nf, tiles_x, tiles_y, tile, head, true);
     __shared__ uint32_t w[2][4];
-    const unsigned long long m = __ballot(walk), mr = __ballot(walk && slot >= nf);
+    const unsigned long long m = __ballot(walk), mr = __ballot(walk && head);
     if ((threadIdx.x & 63u) == 0u) { w[0][threadIdx.x >> 6] = (uint32_t)__popcll(m); w[1][threadIdx.x >> 6] = (uint32_t)__popcll(mr); }
     __syncthreads();
     if (threadIdx.x < 2) block_marked[threadIdx.x * gridDim.x + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
@@ -1135,8 +1159,8 @@ __global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint
     const uint32_t nf = (order_in && n_front_in) ? *n_front_in : 0u;
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     uint32_t tile;
-    const bool walk = compact_slot(ra, order_in, slot, n_in, tiles_x, tiles_y, tile, false);
-    const bool rest = slot >= nf;
+    bool rest;      // to the queue's head
+    const bool walk = compact_slot(ra, order_in, slot, n_in, nf, tiles_x, tiles_y, tile, rest, false);
     // the marked tiles of the workgroups before this one (all of them, and those behind the front), and the latter's total
     uint32_t before = 0u, before_rest = 0u, all_rest = 0u;
     for (uint32_t i = threadIdx.x; i < gridDim.x; i += 256u) {
