@@ -105,7 +105,10 @@ struct hvrt_ctx {
     uint32_t* order_blocks = nullptr; uint64_t order_blocks_capacity = 0;
     uint32_t* split_tiles = nullptr; uint64_t split_tiles_capacity = 0;
     uint32_t* abandoned = nullptr; uint64_t abandoned_capacity = 0;
-    long long abort_ticks = 100000;     // 1 ms of the constant 100 MHz clock; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile
+    // 0.5 ms of the constant 100 MHz clock; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile.  (Launches without history,
+    // the cover worked out by each, at 1000 / 600 / 500 / 420 / 350 / 250 us: config 2 1.09 / 0.95 / 0.86 / 0.80 / 0.86 / 0.90 ms,
+    // config 3 1.86 / 1.81 / 1.70 / 1.99 / 2.58 / 3.78, config 4 16.3 / 14.6 / 13.9 / 15.7 / 15.9 / 18.2)
+    long long abort_ticks = 50000;
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
     hipEvent_t ev_fill_fork = nullptr, ev_fill_join = nullptr;      // k_fill_background runs beside the traversal, on df_stream
     // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
@@ -1193,7 +1196,17 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     ra.split_started = nullptr;
     ra.abandoned = c->abandoned;
     ra.n_abandoned = c->tile_counter + 1;
-    ra.abort_ticks = c->abort_ticks;
+    // (the give-up time grows with the grid: a ray crosses nx + ny + nz voxels at most, and what is "long" for a tile goes with
+    // that -- HVRT_TILE_ABORT_US is the time for grids up to 256^3.  A tile given up on is split from then on, so the time is
+    // also the bar of the launches that follow: config 3, 512^3, with 500 us for all grids: 1.66 ms without history but 0.92-0.97
+    // with, against 1.86 and 0.87)
+    {
+        const GridParams& g = scene_of(c).g;
+        const long long cells = (long long)g.nx + g.ny + g.nz;
+        ra.abort_ticks = cells > 768 ? c->abort_ticks * cells / 768 : c->abort_ticks;
+    }
+    const long long abort_with_cover = ra.abort_ticks;
+    ra.abort_ticks *= 2;      // (every tile walked, the GPU full from end to end: twice the time; halved below where a tile cover is in use)
     ra.tile_cost = c->tile_cost;
     ra.cost_sum = c->cost_sum + c->cost_parity;
     ra.walked = ra.cost_sum + 2;
@@ -1207,6 +1220,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     bool cover_stands = false, fill_beside = false, split_behind_cover = false;
     RenderArgs ra_fill;
     if (use_cover) {
+        ra.abort_ticks = abort_with_cover;
         const uint32_t* const before = c->cover_bits;
         if (int r = ensure<uint32_t>(c, c->cover_bits, c->cover_capacity, cover_words(ca))) return r;
         if (int r = ensure<uint32_t>(c, c->walk_queue, c->walk_queue_capacity, n_tiles)) return r;
@@ -1262,10 +1276,8 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     };
     const bool queued_behind_ev6 = !c->queue_clean;
     if (!c->queue_clean) {
-        HIP_TRY(c, hipMemsetAsync(c->tile_counter, 0, 16 * sizeof(uint32_t), s));   // [0] a single head, [1] abandoned count, [8..15] the heads of segment launches
-        HIP_TRY(c, hipMemsetAsync(c->tile_counter + 64, 0, 8 * 32 * sizeof(uint32_t), s));   // the queue's eight heads, 128 bytes apart
-        HIP_TRY(c, hipMemsetAsync(ra.cost_sum, 0, sizeof(unsigned long long), s));
-        HIP_TRY(c, hipMemsetAsync(ra.walked, 0, sizeof(unsigned long long), s));
+        // [0] a single head, [1] abandoned count, [8..15] the heads of segment launches; the queue's eight heads; the two sums
+        HIP_TRY(c, launch_queue_reset(c->tile_counter, ra.cost_sum, ra.walked, s));
     }
     c->queue_clean = false;
     if (reuse && n_tiles) {
@@ -1341,7 +1353,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             rb.order = c->tile_order;           // any non-null value: "there is a list"
             rb.split_tiles = c->abandoned;
             rb.n_split = ra.n_abandoned;
-            HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s));
+            HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s, nullptr, 0u, true));
         }
     }
     if (fill_beside) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fill_join, 0));

@@ -190,6 +190,8 @@ constexpr int ORDER_ARRAYS = ORDER_BINS + 2;     // count arrays: split, the lon
 hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s);
 // abortable: the kernel may give up on over-long tiles (ra.abandoned); a launch_render_split over that list must follow
 hipError_t launch_render(const SceneDev& sc, const RenderArgs& ra, int n_cus, bool abortable, hipStream_t s);
+// zeroes the queue scratch words a launch starts from ([0, 16), the eight heads), *cost_sum and *walked (nullable)
+hipError_t launch_queue_reset(uint32_t* tile_counter, unsigned long long* cost_sum, unsigned long long* walked, hipStream_t s);
 uint64_t render_tile_count(int width, int local_rows, int n_frames);
 // with ra.cover: the pixels of the tiles the cover does not mark (k_render passes those by); in front of launch_render
 hipError_t launch_fill_background(const RenderArgs& ra, int n_cus, hipStream_t s);
@@ -198,8 +200,9 @@ hipError_t launch_fill_background(const RenderArgs& ra, int n_cus, hipStream_t s
 // duration of zero.  A launch_render over that queue (order = queue, n_queue = counters, n_front = counters + 1) needs no cover.
 hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* block_marked,
                                 uint32_t* queue, uint32_t* counters, hipStream_t s);
+// (alone: nothing runs beside it -- the list of tiles a launch gave up on -- so it may fill the SIMDs: six of its waves each)
 hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups = nullptr,
-                               uint32_t expected_tiles = 0);
+                               uint32_t expected_tiles = 0, bool alone = false);
 // One wave that waits (at most timeout_us) until *started has reached `target` (wrap-around compare): queued in front of
 // a k_render whose k_render_split runs beside it on another stream, so that the split kernel's workgroups are resident
 // before k_render's persistent waves take every slot there is.

@@ -236,7 +236,8 @@ struct TraceResult {
 //
 // ABORT (k_render): a walk that is still inside a list of more than 32 entries when the 100 MHz clock passes `deadline`
 // gives up (tri = HVRT_ABORTED).  The clock is a scalar, so all lanes that are in such a list give up together;
-// the kernel then hands the whole tile to k_render_split.  Lists of up to 32 entries never look at the clock.
+// the kernel then hands the whole tile to k_render_split.  (trace_ray_wave also looks at the clock at every occupied voxel
+// it reaches.)
 constexpr uint32_t HVRT_ABORTED = 0xFFFFFFFEu;
 constexpr uint32_t COST_SPLIT_FLAG = 0x80000000u;   // top bit of a tile's cost word: the tile goes to k_render_split
 template <bool COUNT, bool INLINE, bool NEAREST, int RAYS = 64, bool ABORT = false>
@@ -723,6 +724,9 @@ __device__ __forceinline__ TraceResult trace_ray_wave(const SceneDev& sc, V3 o, 
         if (NEAREST) alive = alive && !done;
         alive = alive && HVRT_IN_GRID();
         if (any_lane(alive) == 0ull) break;
+        // (the give-up variant looks at the clock at every occupied voxel it reaches: a tile of grazing rays is long by the
+        // number of its voxels, whatever the length of their lists)
+        if (ABORT && wall_clock64() > (unsigned long long)deadline) { r.tri = HVRT_ABORTED; return r; }
         uint32_t b0 = 0, b1 = 0;
 #if !defined(HVRT_ABLATE) || HVRT_ABLATE < 2      // ablation builds (timing experiments only): 2 = no lists at all
 #if HVRT_SPEC_OFFSETS
@@ -1632,9 +1636,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_SPLIT_
         }
         const unsigned long long dt = (unsigned long long)(clock64() - clk0) >> 4;
         const uint32_t dc = dt > 0x00FFFFFFull ? 0x00FFFFFFu : (uint32_t)dt;
-        if (lane == 0) atomicAdd(&ra.tile_cost[tile], dc);      // the tile's cost: the sum over its 16 quads
+        // the tile's cost: the sum over its 16 quads
+        if (lane == 0) atomicAdd(&ra.tile_cost[tile], dc);
         wave_cost += dc;
     }
+    // (the quads' durations go into the launch's sum, 16 per tile: the more tiles are split, the higher "the mean walked tile"
+    // and with it the bar for the next one -- without that, every frame of an orbit added its long tiles to the split ones,
+    // which stay split: config 2's orbit 0.71 -> 0.86 ms per frame)
     if (lane == 0 && wave_cost) atomicAdd(ra.cost_sum, wave_cost);
     if (COUNT && ra.counters && !(HVRT_DIAG_BUILD && HVRT_DIAG_NO_SPLIT_COUNTS)) {
         tot_nv = wave_sum64(tot_nv);
@@ -1667,7 +1675,9 @@ __device__ __forceinline__ uint32_t walked_tiles(const unsigned long long* __res
 // What the order build goes by: the wave slots k_render keeps resident, ten times the second split rule's factor, and the
 // lower bounds of the long classes in hundredths of the mean walked tile, highest first.
 // (ten times the factor; with the queue in class order, configs 2 / 3 / 4 at 1.2 / 1.5 / 1.8 / 2.0 / 2.2 / 2.5:
-// 0.91 / 0.55 / 0.52 / 0.52 / 0.53 / 0.52, 0.96 / 0.91 / 0.90 / 0.92 / 0.94 / 1.00 and - / - / 9.9 / 9.6 / 9.5 / 9.4 ms: flat from 1.8 to 2.2)
+// 0.91 / 0.55 / 0.52 / 0.52 / 0.53 / 0.52, 0.96 / 0.91 / 0.90 / 0.92 / 0.94 / 1.00 and - / - / 9.9 / 9.6 / 9.5 / 9.4 ms: flat from 1.8 to 2.2.
+// The mean includes k_render_split's quads, see there; with a mean over k_render's tiles alone and the factor at 2.6 the
+// configs stood at 0.49 / 0.82 / 8.6 ms and an orbit lost a fifth)
 #ifndef HVRT_SPLIT_X10
 #define HVRT_SPLIT_X10 20
 #endif
@@ -1970,14 +1980,14 @@ hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_
 }
 
 hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups,
-                               uint32_t expected_tiles) {
+                               uint32_t expected_tiles, bool alone) {
     if (n_workgroups) *n_workgroups = 0;
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.order) return hipSuccess;
     uint64_t blocks = n_tiles * 4;                         // 16 waves per tile, were every tile split
     // (workgroups per CU at most: 2 / 3 / 4 / 6: config 2 0.63 / 0.51 / 0.49 / 0.51 ms, config 3 0.97 / 0.93 / 0.87 / 0.86,
     // config 4 8.8 throughout)
-    const uint64_t cap = (uint64_t)n_cus * 4u;
+    const uint64_t cap = (uint64_t)n_cus * (alone ? (uint64_t)HVRT_SPLIT_WAVES : 4u);
     if (blocks > cap) blocks = cap;
     // (the caller's idea of how many tiles there are, when it has one: twice the workgroups they need, 16 at least --
     // the items are dealt round-robin, so a count that was too low costs time, not tiles)
@@ -2012,6 +2022,21 @@ __global__ __launch_bounds__(256) void k_warm_scratch(uint32_t* sink, uint32_t n
 hipError_t launch_scratch_warmup(uint32_t* sink, int n_cus, hipStream_t s) {
     const unsigned nb = (unsigned)n_cus * 8u;
     k_warm_scratch<<<nb, 256, 0, s>>>(sink, nb);
+    return hipGetLastError();
+}
+
+// what a launch's queue must find zero (RenderArgs::tile_counter's word map), where no order build has cleared it: one
+// launch instead of four memsets (5 us each on the stream, in front of every launch without history)
+__global__ __launch_bounds__(64) void k_queue_reset(uint32_t* __restrict__ tile_counter, unsigned long long* __restrict__ cost_sum,
+                                                   unsigned long long* __restrict__ walked) {
+    const uint32_t i = threadIdx.x;
+    if (i < 16u) tile_counter[i] = 0u;
+    else if (i < 24u) tile_counter[64u + 32u * (i - 16u)] = 0u;
+    else if (i == 24u) *cost_sum = 0ull;
+    else if (i == 25u && walked) *walked = 0ull;
+}
+hipError_t launch_queue_reset(uint32_t* tile_counter, unsigned long long* cost_sum, unsigned long long* walked, hipStream_t s) {
+    k_queue_reset<<<1, 64, 0, s>>>(tile_counter, cost_sum, walked);
     return hipGetLastError();
 }
 

@@ -45,7 +45,7 @@ ms = []
 for i in range(reps + 2):
     ctx.render_part_device(cam, W, H, spp, 1, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
     ctx.synchronize()
-    if i >= 2: ms.append(ctx.timings().render_ms)
+    if i >= 2 or os.environ.get("HVRT_TIME_LIST"): ms.append(ctx.timings().render_ms)
 if os.environ.get("HVRT_TIME_QUEUED"):        # the same launches queued back to back, waited for once (hvrt_render_history)
     import time
     t0 = time.perf_counter()
@@ -59,5 +59,6 @@ if os.environ.get("HVRT_TIME_QUEUED"):        # the same launches queued back to
         ctx.render_part_device(cam, W, H, spp, 1, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), 0)
         ctx.synchronize()
     print(f"waited for one by one: wall {(time.perf_counter() - t0) * 1e3 / reps:.3f} ms per launch", flush=True)
+if os.environ.get("HVRT_TIME_LIST"): print("launches:", " ".join(f"{v:.2f}" for v in ms), flush=True)
 print(f"render {W}x{H} spp {spp}: mean {np.mean(ms):.3f} ms min {np.min(ms):.3f} ms -> {W*H*spp/np.mean(ms)/1e3:.1f} Mrays/s; checksum hit {int(hit.long().sum())}", flush=True)
 ctx.close()
