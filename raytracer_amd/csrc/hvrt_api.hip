@@ -1313,7 +1313,8 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             // tiles 16 workgroups: 11 ms for a 0.6 ms launch)
             const uint32_t serial_seen = __atomic_load_n(c->split_hint + 1, __ATOMIC_ACQUIRE);
             const uint32_t expected = serial_seen == c->order_serial ? __atomic_load_n(c->split_hint, __ATOMIC_RELAXED) : 0u;
-            HIP_TRY(c, launch_render_split(scene_of(c), rsplit, c->n_cus, c->aux_stream, &nb, expected));
+            // (eight rays per wave unless the grid holds lists of hundreds of entries, see k_render_split)
+            HIP_TRY(c, launch_render_split(scene_of(c), rsplit, c->n_cus, c->aux_stream, &nb, expected, false, c->max_list > 256u ? 4 : 8));
             HIP_TRY(c, hipEventRecord(c->ev_split_join, c->aux_stream));
             if (rsplit.split_started && nb) {
                 // k_render's persistent waves would otherwise take every slot before the split kernel is on (see k_wait_split_started)

@@ -200,9 +200,10 @@ hipError_t launch_fill_background(const RenderArgs& ra, int n_cus, hipStream_t s
 // duration of zero.  A launch_render over that queue (order = queue, n_queue = counters, n_front = counters + 1) needs no cover.
 hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, const uint32_t* n_front_in, uint32_t* block_marked,
                                 uint32_t* queue, uint32_t* counters, hipStream_t s);
-// (alone: nothing runs beside it -- the list of tiles a launch gave up on -- so it may fill the SIMDs: six of its waves each)
+// (alone: nothing runs beside it -- the list of tiles a launch gave up on -- so it may fill the SIMDs: six of its waves each;
+// rays: 4 or 8 rays per wave, i.e. 16 or 8 waves per tile)
 hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups = nullptr,
-                               uint32_t expected_tiles = 0, bool alone = false);
+                               uint32_t expected_tiles = 0, bool alone = false, int rays = 4);
 // One wave that waits (at most timeout_us) until *started has reached `target` (wrap-around compare): queued in front of
 // a k_render whose k_render_split runs beside it on another stream, so that the split kernel's workgroups are resident
 // before k_render's persistent waves take every slot there is.

@@ -375,8 +375,8 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
             // records a lane has to fetch (the loop is bound by L1 data return, 40 B per lane and test).
             const uint32_t n = b1 - b0;
             constexpr uint32_t SLICES = 64u / (uint32_t)RAYS;
-            constexpr uint32_t SLICE_BITS = SLICES == 16u ? 0x00010001u : SLICES == 4u ? 0x11111111u : 0xFFFFFFFFu;
-            static_assert(RAYS == 64 || RAYS == 16 || RAYS == 4, "slice masks are written for 1, 4 and 16 slices");
+            constexpr uint32_t SLICE_BITS = SLICES == 16u ? 0x00010001u : SLICES == 8u ? 0x01010101u : SLICES == 4u ? 0x11111111u : 0xFFFFFFFFu;
+            static_assert(RAYS == 64 || RAYS == 16 || RAYS == 8 || RAYS == 4, "slice masks are written for 1, 4, 8 and 16 slices");
             const uint32_t slice_mask = RAYS == 64 ? 0xFFFFFFFFu : SLICE_BITS << ((threadIdx.x & 63u) / (uint32_t)RAYS);
             for (uint32_t c = 0; c < n; c += 32) {
                 if (ABORT && c != 0u && wall_clock64() > (unsigned long long)deadline) { aborted = true; break; }
@@ -1597,34 +1597,42 @@ __global__ __launch_bounds__(HVRT_RENDER_BLOCK) __attribute__((amdgpu_waves_per_
 // on the skewed 10 M-triangle scene a few tiles cross voxels with thousands of entries and take 7 ms, whatever
 // the frame size, while the rest of the frame is done in 3.  Tiles that the previous launch measured longer than
 // the whole launch would take on a perfectly filled GPU are therefore rendered by this kernel instead: 16 waves per tile, each with a 2x2 pixel quad of it, every ray on 16 lanes that share out the entries
-// of each list (trace_ray, RAYS = 4).  It runs beside k_render on a second stream.  Items are dealt round-robin
+// of each list (trace_ray, RAYS = 4) -- or 8 waves per tile with 4x2 pixels each, eight lanes per ray (SR = 8): half the items,
+// so that config 2's 380 tiles are one round of the kernel's waves instead of one and a half (0.46 -> 0.44 ms); where
+// lists run to hundreds of entries and more the sixteen lanes are worth more (config 3, lists of up to 1 076: the front
+// view 0.86 -> 0.81 ms with eight rays per wave, but the view 20 degrees beside it, across the dense patch, 0.97 -> 1.29;
+// a 9.8 M-triangle scene with lists of up to 3 700: 0.68 -> 0.72), and so they are behind a launch that gave up on
+// tiles, where the kernel has the GPU to itself (config 2: 0.86 against 0.94 ms).  The caller chooses by the grid's
+// longest list.  It runs beside k_render on a second stream.  Items are dealt round-robin
 // with a bounded loop (no queue): they are few and of one kind.
-template <bool COUNT, bool INLINE, bool NEAREST>
+template <bool COUNT, bool INLINE, bool NEAREST, int SR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HVRT_SPLIT_WAVES, HVRT_SPLIT_WAVES))) void k_render_split(SceneDev sc, RenderArgs ra) {
     const int lane = threadIdx.x & 63;
-    const int ray = lane & 3, slice = lane >> 2;
+    // SR, rays per wave: 4 (2 x 2 pixels, 16 waves per tile) or 8 (4 x 2 pixels, 8 waves per tile)
+    constexpr uint32_t PER_TILE = 64u / (uint32_t)SR;    // items per tile
+    const int ray = lane & (SR - 1), slice = lane / SR;
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t tiles_frame = tiles_x * tiles_y;
     if (ra.split_started && threadIdx.x == 0) atomicAdd(ra.split_started, 1u);      // "this workgroup has a place on the GPU"
-    const uint32_t n_items = *ra.n_split * 16u;
-    if (ra.walked && blockIdx.x == 0 && threadIdx.x == 0 && n_items) atomicAdd(ra.walked, (unsigned long long)(n_items >> 4));
+    const uint32_t n_items = *ra.n_split * PER_TILE;
+    if (ra.walked && blockIdx.x == 0 && threadIdx.x == 0 && n_items) atomicAdd(ra.walked, (unsigned long long)(n_items / PER_TILE));
     const uint32_t wave0 = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
     uint64_t tot_nv = 0, tot_nt = 0;
     unsigned long long wave_cost = 0;
     for (uint32_t item = wave0; item < n_items; item += n_waves) {
         const long long clk0 = clock64();
         const long long wall0 = 0;      // this kernel never gives up
-        const uint32_t tile = ra.split_tiles[item >> 4], quad = item & 15u;
+        const uint32_t tile = ra.split_tiles[item / PER_TILE], quad = item % PER_TILE;
         const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
         const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
-        const int x = (int)(tx * 8u) + (int)(quad & 3u) * 2 + (ray & 1);
-        const int lr = (int)(ty * 8u) + (int)(quad >> 2) * 2 + (ray >> 1);
+        const int x = SR == 4 ? (int)(tx * 8u) + (int)(quad & 3u) * 2 + (ray & 1) : (int)(tx * 8u) + (int)(quad & 1u) * 4 + (ray & 3);
+        const int lr = SR == 4 ? (int)(ty * 8u) + (int)(quad >> 2) * 2 + (ray >> 1) : (int)(ty * 8u) + (int)(quad >> 1) * 2 + (ray >> 2);
         const int kl = lr / ra.tile_rows;
         const int y = (kl * ra.n_parts + ra.part) * ra.tile_rows + (lr - kl * ra.tile_rows);
         if (x < ra.width && lr < ra.local_rows && y < ra.height) {
             PixelResult px;
-            render_pixel<COUNT, INLINE, NEAREST, 4, false>(sc, ra, ra.frames ? ra.frames + fi : nullptr, 0u, 0u, lane, x, y, true, nullptr, wall0, px);
+            render_pixel<COUNT, INLINE, NEAREST, SR, false>(sc, ra, ra.frames ? ra.frames + fi : nullptr, 0u, 0u, lane, x, y, true, nullptr, wall0, px);
             if (slice == 0) {
                 store_pixel(ra, fi, lr, x, px);
                 if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
@@ -1980,22 +1988,23 @@ hipError_t launch_wait_split_started(uint32_t* started, uint32_t target, uint32_
 }
 
 hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_cus, hipStream_t s, uint32_t* n_workgroups,
-                               uint32_t expected_tiles, bool alone) {
+                               uint32_t expected_tiles, bool alone, int rays) {
     if (n_workgroups) *n_workgroups = 0;
     const uint64_t n_tiles = render_tile_count(ra.width, ra.local_rows, ra.n_frames);
     if (n_tiles == 0 || !ra.order) return hipSuccess;
-    uint64_t blocks = n_tiles * 4;                         // 16 waves per tile, were every tile split
+    const uint64_t WG_PER_TILE = rays == 8 ? 2u : 4u;      // 64 / rays waves per tile, four waves per workgroup
+    uint64_t blocks = n_tiles * WG_PER_TILE;               // were every tile split
     // (workgroups per CU at most: 2 / 3 / 4 / 6: config 2 0.63 / 0.51 / 0.49 / 0.51 ms, config 3 0.97 / 0.93 / 0.87 / 0.86,
     // config 4 8.8 throughout)
     const uint64_t cap = (uint64_t)n_cus * (alone ? (uint64_t)HVRT_SPLIT_WAVES : 4u);
     if (blocks > cap) blocks = cap;
     // (the caller's idea of how many tiles there are, when it has one: twice the workgroups they need, 16 at least --
     // the items are dealt round-robin, so a count that was too low costs time, not tiles)
-    if (expected_tiles && (uint64_t)expected_tiles * 8u < blocks) blocks = expected_tiles * 8u < 16u ? 16u : expected_tiles * 8u;
+    if (expected_tiles && (uint64_t)expected_tiles * 2u * WG_PER_TILE < blocks) blocks = expected_tiles * 2u * WG_PER_TILE < 16u ? 16u : expected_tiles * 2u * WG_PER_TILE;
     const bool il = sc.ref_rec != nullptr;
     const unsigned nb = (unsigned)blocks;
     if (n_workgroups) *n_workgroups = nb;
-#define HVRT_LAUNCH(C, I, N) k_render_split<C, I, N><<<nb, 256, 0, s>>>(sc, ra)
+#define HVRT_LAUNCH(C, I, N) do { if (rays == 8) k_render_split<C, I, N, 8><<<nb, 256, 0, s>>>(sc, ra); else k_render_split<C, I, N, 4><<<nb, 256, 0, s>>>(sc, ra); } while (0)
     if (ra.nearest) {
         if (ra.counters) { if (il) HVRT_LAUNCH(true, true, true); else HVRT_LAUNCH(true, false, true); }
         else             { if (il) HVRT_LAUNCH(false, true, true); else HVRT_LAUNCH(false, false, true); }
