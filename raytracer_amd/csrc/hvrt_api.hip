@@ -1224,7 +1224,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         const uint32_t* const before = c->cover_bits;
         if (int r = ensure<uint32_t>(c, c->cover_bits, c->cover_capacity, cover_words(ca))) return r;
         if (int r = ensure<uint32_t>(c, c->walk_queue, c->walk_queue_capacity, n_tiles)) return r;
-        if (int r = ensure<uint32_t>(c, c->compact_counts, c->compact_counts_capacity, 2 * order_blocks)) return r;
+        if (int r = ensure<uint32_t>(c, c->compact_counts, c->compact_counts_capacity, 2 * order_blocks + 1)) return r;
         const CoverArgs& l = c->cover_last;
         cover_stands = c->cover_cache && before == c->cover_bits && l.n_frames == n_frames && l.width == width && l.height == height &&
                        memcmp(c->cover_frames, frames, sizeof(hvrt_camera_frame) * (size_t)n_frames) == 0;

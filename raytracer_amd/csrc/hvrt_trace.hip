@@ -1150,12 +1150,35 @@ __global__ __launch_bounds__(256) void k_compact_count(RenderArgs ra, const uint
     __syncthreads();
     if (threadIdx.x < 2) block_marked[threadIdx.x * gridDim.x + blockIdx.x] = w[threadIdx.x][0] + w[threadIdx.x][1] + w[threadIdx.x][2] + w[threadIdx.x][3];
 }
+// Frames by the dozen make tens of thousands of workgroups, and every one adding up all the counts before its own is
+// quadratic (32 frames of 8K: 8 G loads); from COMPACT_SCAN_FROM workgroups on, one launch in between turns the two arrays
+// into exclusive prefixes (one workgroup each) and leaves the second array's total in word [2 n].
+constexpr uint32_t COMPACT_SCAN_FROM = 1024u;
+__global__ __launch_bounds__(1024) void k_compact_scan(uint32_t* __restrict__ block_marked, uint32_t n_blocks) {
+    uint32_t* __restrict__ a = block_marked + blockIdx.x * n_blocks;
+    __shared__ uint32_t sh[1024];
+    const uint32_t per = (n_blocks + 1023u) / 1024u;
+    const uint32_t b0 = threadIdx.x * per, b = b0 < n_blocks ? b0 : n_blocks, e = b + per < n_blocks ? b + per : n_blocks;
+    uint32_t sum = 0;
+    for (uint32_t i = b; i < e; ++i) sum += a[i];
+    sh[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const uint32_t o = threadIdx.x >= (unsigned)d ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += o;
+        __syncthreads();
+    }
+    uint32_t run = sh[threadIdx.x] - sum;
+    for (uint32_t i = b; i < e; ++i) { const uint32_t v = a[i]; a[i] = run; run += v; }
+    if (threadIdx.x == 1023 && blockIdx.x == 1) block_marked[2u * n_blocks] = sh[1023];
+}
 // The queue: first the marked tiles from behind order_in's front -- tiles the launch that left the order did not walk, or
 // hardly: with a camera that moves they are the new silhouette, the longest tiles of the frame for all anyone knows, and at
 // the queue's end they were what an orbit's launches ended with (config 2: k_render 556 us with them last, the rest of
 // the queue done after 355) -- then the front's marked tiles, both in order_in's order.
 __global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint32_t* __restrict__ order_in, const uint32_t* __restrict__ n_front_in,
-                                                      const uint32_t* __restrict__ block_marked, uint32_t* __restrict__ queue, uint32_t* __restrict__ counters) {
+                                                      const uint32_t* __restrict__ block_marked, bool scanned, uint32_t* __restrict__ queue, uint32_t* __restrict__ counters) {
     const uint32_t tiles_x = (uint32_t)(ra.width + 7) >> 3;
     const uint32_t tiles_y = (uint32_t)(ra.local_rows + 7) >> 3;
     const uint32_t n_tiles = tiles_x * tiles_y * (uint32_t)ra.n_frames;
@@ -1167,10 +1190,15 @@ __global__ __launch_bounds__(256) void k_compact_queue(RenderArgs ra, const uint
     const bool walk = compact_slot(ra, order_in, slot, n_in, nf, tiles_x, tiles_y, tile, rest, false);
     // the marked tiles of the workgroups before this one (all of them, and those behind the front), and the latter's total
     uint32_t before = 0u, before_rest = 0u, all_rest = 0u;
-    for (uint32_t i = threadIdx.x; i < gridDim.x; i += 256u) {
-        const uint32_t r = block_marked[gridDim.x + i];
-        all_rest += r;
-        if (i < blockIdx.x) { before += block_marked[i]; before_rest += r; }
+    if (scanned) {
+        // (k_compact_scan has been over the two arrays: exclusive prefixes, the second array's total behind it)
+        if (threadIdx.x == 0) { before = block_marked[blockIdx.x]; before_rest = block_marked[gridDim.x + blockIdx.x]; all_rest = block_marked[2u * gridDim.x]; }
+    } else {
+        for (uint32_t i = threadIdx.x; i < gridDim.x; i += 256u) {
+            const uint32_t r = block_marked[gridDim.x + i];
+            all_rest += r;
+            if (i < blockIdx.x) { before += block_marked[i]; before_rest += r; }
+        }
     }
     before = (uint32_t)wave_sum64(before); before_rest = (uint32_t)wave_sum64(before_rest); all_rest = (uint32_t)wave_sum64(all_rest);      // (lane 0 holds the sums)
     __shared__ uint32_t w[2][4], wb[3][4];
@@ -1944,7 +1972,9 @@ hipError_t launch_compact_queue(const RenderArgs& ra, const uint32_t* order_in, 
     if (n_tiles == 0 || !ra.cover || !block_marked) return hipErrorInvalidValue;
     const unsigned nb = (unsigned)((n_tiles + 255) / 256);
     k_compact_count<<<nb, 256, 0, s>>>(ra, order_in, n_front_in, block_marked);
-    k_compact_queue<<<nb, 256, 0, s>>>(ra, order_in, n_front_in, block_marked, queue, counters);
+    const bool scan = nb >= COMPACT_SCAN_FROM;
+    if (scan) k_compact_scan<<<2, 1024, 0, s>>>(block_marked, nb);
+    k_compact_queue<<<nb, 256, 0, s>>>(ra, order_in, n_front_in, block_marked, scan, queue, counters);
     return hipGetLastError();
 }
 

@@ -228,6 +228,37 @@ def test_batch_launch_equals_single_launches_and_order_changes_nothing(ctx, n_pa
         ctx.render_batch_part_device(cams * 9, W, H, 1, 0, tile_rows, part, n_parts, slab, d_rgb=batch.data_ptr())
 
 
+def test_batch_of_many_tiles_takes_the_scanned_queue_compaction(ctx):
+    """32 frames of 1024x520 are 266 240 tiles = 1040 workgroups for the queue's compaction: from 1024 on k_compact_scan turns
+    the per-workgroup counts into prefixes in one launch (instead of every workgroup adding up all the counts before its
+    own).  Same bytes as the launches one by one, on the launch without history and on two with it."""
+    import torch
+    tris = meshgen.cube_sphere(16)
+    sc, mn, mx = setup_scene(ctx, tris, (24, 24, 24))
+    W, H, n = 1024, 520, 32
+    views = ("front", "side", "top")
+    cams = [capi.make_camera_frame(*capi.default_camera(mn, mx, views[f % 3])) for f in range(n)]
+    dev = torch.device("cuda:0")
+    single = torch.zeros((3, H, W, 3), dtype=torch.float32, device=dev)
+    single_hit = torch.zeros((3, H, W), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for f in range(3):
+        ctx.render_part_device(cams[f], W, H, 1, 0, H, 0, 1, d_rgb=single[f].data_ptr(), d_hit=single_hit[f].data_ptr())
+    ctx.synchronize()
+    want, want_hit = single.cpu().numpy().view(np.uint32), single_hit.cpu().numpy()
+    assert int((want_hit != -1).sum()) > 1000
+    for rep in range(3):
+        batch = torch.zeros((n, H, W, 3), dtype=torch.float32, device=dev)
+        batch_hit = torch.zeros((n, H, W), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.render_batch_part_device(cams, W, H, 1, 0, H, 0, 1, H, d_rgb=batch.data_ptr(), d_hit=batch_hit.data_ptr())
+        ctx.synchronize()
+        got, got_hit = batch.cpu().numpy().view(np.uint32), batch_hit.cpu().numpy()
+        for f in range(n):
+            assert np.array_equal(got[f], want[f % 3]), f"rgb differs, frame {f}, launch {rep}"
+            assert np.array_equal(got_hit[f], want_hit[f % 3]), f"hit ids differ, frame {f}, launch {rep}"
+
+
 def test_launches_queued_without_waiting_keep_their_durations_and_their_bytes(ctx):
     """hvrt_render_history: launches queued back to back (what bench.py's timed region does) are each bracketed by their
     own pair of events -- the last 32 are kept -- and every one of them writes the frame the first one wrote."""
