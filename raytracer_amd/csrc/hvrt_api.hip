@@ -109,6 +109,7 @@ struct hvrt_ctx {
     // the cover worked out by each, at 1000 / 600 / 500 / 420 / 350 / 250 us: config 2 1.09 / 0.95 / 0.86 / 0.80 / 0.86 / 0.90 ms,
     // config 3 1.86 / 1.81 / 1.70 / 1.99 / 2.58 / 3.78, config 4 16.3 / 14.6 / 13.9 / 15.7 / 15.9 / 18.2)
     long long abort_ticks = 50000;
+    uint32_t few_tiles = 2048;           // HVRT_FEW_TILES (RenderArgs::few_tiles)
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
     hipEvent_t ev_fill_fork = nullptr, ev_fill_join = nullptr;      // k_fill_background runs beside the traversal, on df_stream
     // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
@@ -523,6 +524,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
         const long long us = atoll(v);
         c->abort_ticks = us > 0 ? (us < (1ll << 40) ? us * 100 : (1ll << 47)) : 0;      // 0: the plain kernel is launched
     }
+    if (const char* v = getenv("HVRT_FEW_TILES")) { const long long n = atoll(v); c->few_tiles = n > 0 ? (uint32_t)(n < 0x7FFFFFFF ? n : 0x7FFFFFFF) : 0u; }
     if ((e = hipMalloc((void**)&c->counters, 256)) != hipSuccess) return bail("hipMalloc", e);
     // the download ring belongs to the construction of a tracer, not to its first render()
     if ((e = hipHostMalloc((void**)&c->pin_ring, hvrt_ctx::PIN_CHUNK * hvrt_ctx::PIN_RING, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
@@ -1205,6 +1207,7 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         const long long cells = (long long)g.nx + g.ny + g.nz;
         ra.abort_ticks = cells > 768 ? c->abort_ticks * cells / 768 : c->abort_ticks;
     }
+    ra.few_tiles = c->few_tiles;
     const long long abort_with_cover = ra.abort_ticks;
     ra.abort_ticks *= 2;      // (every tile walked, the GPU full from end to end: twice the time; halved below where a tile cover is in use)
     ra.tile_cost = c->tile_cost;
@@ -1354,7 +1357,10 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
             rb.order = c->tile_order;           // any non-null value: "there is a list"
             rb.split_tiles = c->abandoned;
             rb.n_split = ra.n_abandoned;
-            HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s, nullptr, 0u, true));
+            // (eight rays per wave where the grid's lists are short, as beside k_render: since the split kernel's walk looks ahead, the
+            // sixteen lanes per ray no longer pay behind a launch either -- config 2 at 800x600, every tile given up for being few:
+            // 0.48 -> 0.43 ms, at 4K 0.83 either way)
+            HIP_TRY(c, launch_render_split(scene_of(c), rb, c->n_cus, s, nullptr, 0u, true, c->max_list > 256u ? 4 : 8));
         }
     }
     if (fill_beside) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_fill_join, 0));
@@ -1521,7 +1527,7 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
     ra.n_heads = 1;
     ra.order = nullptr;                 // no history is kept between these calls: rows of tiles from the middle outwards
     ra.split_tiles = nullptr; ra.n_split = nullptr;
-    ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_ticks = 0;   // the plain kernel: no tile is handed on
+    ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_ticks = 0; ra.few_tiles = 0;   // the plain kernel: no tile is handed on
     ra.tile_cost = (uint32_t*)(sp + NOALLOC_TILE_COST);
     ra.cost_sum = (unsigned long long*)(sp + NOALLOC_COST_SUM);
     // the array keeps the last call's contents: the queue head and the duration sum must start at zero (the

@@ -100,6 +100,10 @@ struct RenderArgs {
     uint32_t* abandoned;
     uint32_t* n_abandoned;
     long long abort_ticks;   // in ticks of the constant 100 MHz clock (wall_clock64), per sample of a pixel
+    // A launch without history whose queue (n_queue: the marked tiles) holds at most few_tiles tiles gives every tile up at the
+    // first occupied voxel its rays reach: the GPU is all but empty, and k_render_split behind it walks each tile with
+    // sixteen waves that look ahead (trace_ray_ahead) instead of one that cannot.  0: never.
+    uint32_t few_tiles;
     uint32_t* tile_cost;
     unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
     unsigned long long* walked;     // (nullable) += the tiles this launch walked (zeroed before it; the order build reads it at cost_sum[2])

@@ -457,6 +457,136 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneDev& sc, V3 o, V3 d,
     return r;
 }
 
+// ---- the same walk, looking ahead (k_render_split, mode 0, no counters) ---------------------------------------
+// What a launch waits for in the end is a handful of ray packets that graze the occupied shell: some hundred voxels one
+// after the other, each a look-up that depends on the step before it and, where the voxel holds a list, a second one for
+// its records -- 0.5 to 1 us apiece with the GPU three quarters idle (scripts/tile_starts.py: the longest 4x2-pixel piece of
+// config 2's front view takes 350 us, whatever the frame size).  But a ray's voxel sequence does not depend on what the
+// voxels hold: the DDA's steps are arithmetic on the ray alone.  So the walk takes HVRT_LOOKAHEAD steps first, remembers
+// the voxels (and the face each was entered through), fetches all their list bounds with loads that are in flight
+// together, and then looks at the voxels in the ray's order: the first one with a hit ends the ray, exactly as in trace_ray
+// -- same voxel sequence, same tests in the same order, same result bit for bit; the steps taken beyond the voxel that
+// ends a ray are thrown away with the ray's state.  The distance field is consulted for the last voxel of a batch only:
+// dist - 1 further voxels are empty whatever the ray does, and are stepped through without being looked at (32 at most,
+// as in trace_ray).
+#ifndef HVRT_LOOKAHEAD
+#define HVRT_LOOKAHEAD 2      // (0: off.  Configs 2 / 3 with 0 / 2 / 4 / 8 voxels and the split bar where it is best for each: 0.44 / 0.415 / 0.42 / 0.43 and 0.875 / 0.80 / 0.82 / 0.91 ms)
+#endif
+template <bool INLINE, int RAYS>
+__device__ __forceinline__ TraceResult trace_ray_ahead(const SceneDev& sc, V3 o, V3 d) {
+    static_assert(RAYS == 16 || RAYS == 8 || RAYS == 4, "the slices of a ray share out every list");
+    constexpr int N = HVRT_LOOKAHEAD > 0 ? HVRT_LOOKAHEAD : 1;      // (0: render_pixel does not call this)
+    const GridParams& g = sc.g;
+    TraceResult r;
+    r.tri = HVRT_MISS; r.t = FLT_MAX; r.nv = 0; r.nt = 0;
+    // initializeTraversal, :155-195, as in trace_ray
+    const int ix = clampi(f2i((o.x - g.mnx) / g.vsx), 0, g.nx - 1);
+    const int iy = clampi(f2i((o.y - g.mny) / g.vsy), 0, g.ny - 1);
+    const int iz = clampi(f2i((o.z - g.mnz) / g.vsz), 0, g.nz - 1);
+    const bool px = d.x > 0.0f, py = d.y > 0.0f, pz = d.z > 0.0f;
+    const float tdx = fabsf(g.vsx / d.x), tdy = fabsf(g.vsy / d.y), tdz = fabsf(g.vsz / d.z);
+    float tmx = ((g.mnx + (float)(px ? ix + 1 : ix) * g.vsx) - o.x) / d.x;
+    float tmy = ((g.mny + (float)(py ? iy + 1 : iy) * g.vsy) - o.y) / d.y;
+    float tmz = ((g.mnz + (float)(pz ? iz + 1 : iz) * g.vsz) - o.z) / d.z;
+    int rx = px ? g.nx - 1 - ix : ix;
+    int ry = py ? g.ny - 1 - iy : iy;
+    const int zsum = (pz ? g.nz - 1 - iz : iz) + rx + ry;
+    int tot = 0;
+    const uint32_t plane = (uint32_t)g.nx * (uint32_t)g.ny;
+    const uint32_t fsx = px ? 1u : 0xFFFFFFFFu;
+    const uint32_t fsy = py ? (uint32_t)g.nx : 0u - (uint32_t)g.nx;
+    const uint32_t fsz = pz ? plane : 0u - plane;
+    uint32_t f = (uint32_t)ix + (uint32_t)g.nx * (uint32_t)iy + plane * (uint32_t)iz;
+    const uint32_t* __restrict__ offs = sc.offsets;
+    const uint8_t* __restrict__ dist = sc.dist;
+    const uint32_t fw = (uint32_t)sc.face_words;
+    const uint32_t facex = (px ? 0u : 1u) * fw, facey = (py ? 2u : 3u) * fw, facez = (pz ? 4u : 5u) * fw;
+    uint32_t last = 0;
+    constexpr uint32_t SLICES = 64u / (uint32_t)RAYS;
+    constexpr uint32_t SLICE_BITS = SLICES == 16u ? 0x00010001u : SLICES == 8u ? 0x01010101u : 0x11111111u;
+    const uint32_t slice_mask = SLICE_BITS << ((threadIdx.x & 63u) / (uint32_t)RAYS);
+#define HVRT_IN_GRID() ((rx | ry | (zsum - tot - rx - ry)) >= 0)
+    bool in_grid = true;      // the start voxel is clamped into the grid
+    for (;;) {
+        // the ray's next N voxels, from the steps alone (a voxel behind the grid's edge is remembered as such, not looked at)
+        uint32_t qf[N], ql[N];
+        bool qv[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            qf[i] = f; ql[i] = last; qv[i] = in_grid;
+            HVRT_STEP();
+            ++tot;
+            in_grid = in_grid && HVRT_IN_GRID();
+        }
+        uint32_t qb0[N], qb1[N], dd = 0u;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            qb0[i] = 0u; qb1[i] = 0u;
+            if (qv[i]) { const uint32_t* pv = offs + qf[i]; qb0[i] = pv[0]; qb1[i] = pv[1]; }
+        }
+        if (in_grid) dd = dist[qf[N - 1]];      // (in_grid: voxel N - 1 and the one behind it are in the grid)
+        bool ended = false;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (ended) break;
+            if (!qv[i]) { ended = true; break; }          // the ray left the grid before this voxel
+            const uint32_t b0 = qb0[i], n = qb1[i] - qb0[i];
+            if (n == 0u) continue;
+            // testVoxelTriangles, :267-295, as in trace_ray: every entry is tested, the LAST one that hits wins
+            const bool entered = ql[i] != 0u;
+            const uint32_t face = sel(any_lane(ql[i] == fsx) & (g.nx > 1 ? ~0ull : 0ull), facex, sel(any_lane(ql[i] == fsy) & (g.ny > 1 ? ~0ull : 0ull), facey, facez));
+            uint32_t bkey = 0;
+            for (uint32_t c = 0; c < n; c += 32) {
+                const uint32_t base = b0 + c;
+                uint32_t skip = 0;
+                if (entered) {
+                    const uint32_t* __restrict__ fb = sc.face_bits + (face + (base >> 5));
+                    skip = __builtin_amdgcn_alignbit(fb[1], fb[0], base & 31u);
+                }
+                const uint32_t left = n - c;
+                uint32_t todo = ~skip & (left >= 32 ? 0xFFFFFFFFu : ((1u << left) - 1u)) & slice_mask;
+                while (todo) {
+                    const uint32_t k = (uint32_t)__builtin_ctz(todo);
+                    todo &= todo - 1;
+                    const uint32_t j = base + k;
+                    if (INLINE) {
+                        const float4* __restrict__ rec = sc.ref_rec + 3ull * j;
+                        const float4 c0 = rec[0], c1 = rec[1];
+                        const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
+                        ray_triangle({ c0.x, c0.y, c0.z }, { c0.w, c1.x, c1.y }, { c1.z, c1.w, e2z }, o, d, [&](float t) {
+                            r.tri = __float_as_uint(reinterpret_cast<const float*>(rec + 2)[1]); r.t = t;
+                            bkey = c + k + 1u;
+                        });
+                    } else {
+                        const uint32_t ti = sc.indices[j];
+                        const float4 r0 = sc.tri_rec[3ull * ti], r1 = sc.tri_rec[3ull * ti + 1];
+                        const float e2z = reinterpret_cast<const float*>(sc.tri_rec + 3ull * ti + 2)[0];
+                        ray_triangle({ r0.x, r0.y, r0.z }, { r0.w, r1.x, r1.y }, { r1.z, r1.w, e2z }, o, d, [&](float t) {
+                            r.tri = ti; r.t = t;
+                            bkey = c + k + 1u;
+                        });
+                    }
+                }
+            }
+            // the slices' candidates: the highest entry that hit is the one the sequential loop would have kept
+#pragma unroll
+            for (int m = RAYS; m < 64; m <<= 1) {
+                const uint32_t ok = (uint32_t)__shfl_xor((int)bkey, m), otri = (uint32_t)__shfl_xor((int)r.tri, m);
+                const float ot = __shfl_xor(r.t, m);
+                if (ok > bkey) { bkey = ok; r.tri = otri; r.t = ot; }
+            }
+            if (r.tri != HVRT_MISS) ended = true;      // :326-329
+        }
+        if (ended || !in_grid) break;
+        // open space behind the batch's last voxel: dd - 1 voxels that hold nothing
+        const int run = dd > 33u ? 32 : (int)dd - 1;
+        for (int i = 0; i < run; ++i) { HVRT_STEP(); }
+        if (run > 0) { tot += run; in_grid = HVRT_IN_GRID(); if (!in_grid) break; }
+    }
+#undef HVRT_IN_GRID
+    return r;
+}
+
 // ---- wave-synchronous traversal on per-reference records (k_render, k_trace) ---------------------------
 // The same walk as trace_ray<..., INLINE = true, ..., RAYS = 64>, written so that the wave's control flow is
 // UNIFORM: the outer loop, the list loop and the chunk loop branch on ballots, and a ray that has ended (or a
@@ -982,6 +1112,7 @@ __device__ __forceinline__ bool render_pixel(const SceneDev& sc, const RenderArg
             tile_box(d, win + 64);
             r = trace_ray_wave<COUNT, NEAREST, ABORT, true>(sc, org, d, alive, win, wall0 + ra.abort_ticks * (s + 1));
         }
+        else if constexpr (!COUNT && !NEAREST && !ABORT && RAYS < 64 && HVRT_LOOKAHEAD > 0) r = trace_ray_ahead<INLINE, RAYS>(sc, org, d);
         else r = trace_ray<COUNT, INLINE, NEAREST, RAYS, ABORT>(sc, org, d, wall0 + ra.abort_ticks * (s + 1));
         if (ABORT && r.tri == HVRT_ABORTED) return false;
         const V3 c = shade(sc, r, org, v);
@@ -1504,7 +1635,8 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
         const long long clk0 = clock64();
         // the give-up deadline runs on the constant 100 MHz clock (s_memrealtime): the shader clock, which prices the
         // tiles, moves with the chip's power state
-        const long long wall0 = ABORT ? (long long)wall_clock64() : 0;
+        // (few tiles in the whole queue: a deadline that has passed, see RenderArgs::few_tiles)
+        const long long wall0 = ABORT ? (ra.n_queue && n_queue <= ra.few_tiles ? 0ll : (long long)wall_clock64()) : 0;
         const unsigned long long debug_wall0 = ra.debug_start ? wall_clock64() : 0ull;      // (a diagnostic: when the tile started, 10-ns ticks)
         const uint32_t fi = tile / tiles_frame, tf = tile - fi * tiles_frame;
         const uint32_t ty = tf / tiles_x, tx = tf - ty * tiles_x;
@@ -1550,7 +1682,7 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
 #if defined(HVRT_DIAG) && HVRT_DIAG == 41
             ++n_done;
 #endif
-            if (dropped) given_up = tile;                       // appended to the list by the next iteration
+            if (dropped) { given_up = tile; --n_walked; }        // appended to the list by the next iteration; k_render_split counts it among the walked
 #if !defined(HVRT_DIAG) || (HVRT_DIAG != 31 && HVRT_DIAG != 32 && HVRT_DIAG != 33 && HVRT_DIAG != 34)
             else if (COUNT) { tot_nv += px.nv; tot_nt += px.nt; }
 #endif
@@ -1715,7 +1847,7 @@ __device__ __forceinline__ uint32_t walked_tiles(const unsigned long long* __res
 // The mean includes k_render_split's quads, see there; with a mean over k_render's tiles alone and the factor at 2.6 the
 // configs stood at 0.49 / 0.82 / 8.6 ms and an orbit lost a fifth)
 #ifndef HVRT_SPLIT_X10
-#define HVRT_SPLIT_X10 20
+#define HVRT_SPLIT_X10 18
 #endif
 #ifndef HVRT_ORDER_CLASSES
 #define HVRT_ORDER_CLASSES ORDER_BINS      // long classes in use (1: the tiles above the first bound only)

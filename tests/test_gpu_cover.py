@@ -209,7 +209,8 @@ def test_cover_follows_the_mesh_under_a_camera_that_stands(ctx):
 
 
 @pytest.mark.parametrize("env", [{"HVRT_TILE_COVER": "0"}, {"HVRT_TILE_COVER_CACHE": "0"}, {"HVRT_SAMPLE_SPLIT": "0"},
-                                 {"HVRT_TILE_SPLIT": "0"}, {"HVRT_TILE_ORDER": "0"}, {"HVRT_WARMUP": "0", "HVRT_TILE_ABORT_US": "1"}],
+                                 {"HVRT_TILE_SPLIT": "0"}, {"HVRT_TILE_ORDER": "0"}, {"HVRT_WARMUP": "0", "HVRT_TILE_ABORT_US": "1"},
+                                 {"HVRT_FEW_TILES": "0"}, {"HVRT_FEW_TILES": "1000000"}, {"HVRT_FEW_TILES": "1000000", "HVRT_TILE_ORDER": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_plain_launches_under_the_switches(monkeypatch, env):
     """The launches without counters (the ones the cover, the queue of marked tiles and the split by sample belong to) under

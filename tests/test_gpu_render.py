@@ -601,7 +601,8 @@ def test_config4_8k_16spp_rows(ctx):
 SWITCHES = [{"HVRT_WARMUP": "0"}, {"HVRT_TILE_SPLIT": "0"}, {"HVRT_TILE_ORDER": "0"}, {"HVRT_SPLIT_WAIT": "0"},
             {"HVRT_TILE_ABORT_US": "0"}, {"HVRT_HISTORY_MAX_DEG": "0"}, {"HVRT_WARMUP": "0", "HVRT_TILE_ABORT_US": "1"},
             {"HVRT_DF_LOW_PRIORITY": "1"}, {"HVRT_INLINE_RECORDS": "0"}, {"HVRT_TRACE_BUILD": "1", "HVRT_TRACE_TIMES": "1"},
-            {"HVRT_BUILD_NARROW": "0", "HVRT_BUILD_REUSE": "0"}]
+            {"HVRT_BUILD_NARROW": "0", "HVRT_BUILD_REUSE": "0"}, {"HVRT_FEW_TILES": "0"},
+            {"HVRT_FEW_TILES": "1000000", "HVRT_INLINE_RECORDS": "0"}]
 
 
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
