@@ -105,10 +105,10 @@ struct hvrt_ctx {
     uint32_t* order_blocks = nullptr; uint64_t order_blocks_capacity = 0;
     uint32_t* split_tiles = nullptr; uint64_t split_tiles_capacity = 0;
     uint32_t* abandoned = nullptr; uint64_t abandoned_capacity = 0;
-    // 0.5 ms of the constant 100 MHz clock; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile.  (Launches without history,
-    // the cover worked out by each, at 1000 / 600 / 500 / 420 / 350 / 250 us: config 2 1.09 / 0.95 / 0.86 / 0.80 / 0.86 / 0.90 ms,
+    // 0.3 ms of the constant 100 MHz clock; HVRT_TILE_ABORT_US sets it, 0 = never give up on a tile.  (Before k_render_split's walk
+    // looked ahead it was 0.5 ms: launches without history, the cover worked out by each, at 1000 / 600 / 500 / 420 / 350 / 250 us: config 2 1.09 / 0.95 / 0.86 / 0.80 / 0.86 / 0.90 ms,
     // config 3 1.86 / 1.81 / 1.70 / 1.99 / 2.58 / 3.78, config 4 16.3 / 14.6 / 13.9 / 15.7 / 15.9 / 18.2)
-    long long abort_ticks = 50000;
+    long long abort_ticks = 30000;       // HVRT_TILE_ABORT_US: 300 us (see render_batch_part)
     uint32_t few_tiles = 2048;           // HVRT_FEW_TILES (RenderArgs::few_tiles)
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
     hipEvent_t ev_fill_fork = nullptr, ev_fill_join = nullptr;      // k_fill_background runs beside the traversal, on df_stream
@@ -1206,6 +1206,12 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         const GridParams& g = scene_of(c).g;
         const long long cells = (long long)g.nx + g.ny + g.nz;
         ra.abort_ticks = cells > 768 ? c->abort_ticks * cells / 768 : c->abort_ticks;
+        // (Since k_render_split's walk looks ahead, a tile is better off there sooner: launches without history at 500 / 420 /
+        // 350 / 300 / 250 / 200 us: config 2 0.82 / 0.74 / 0.68 / 0.63 / 0.60 / 0.78 ms, config 3 1.76 / 1.60 / 1.51 / 1.41 / 1.48 /
+        // 1.65, config 4 10.3 / 10.3 / 10.3 / 11.4 / 11.5 / 11.7; with history 250 us costs configs 2 and 3 some 4 %, 300 us
+        // nothing.  Supersampled launches, whose long tiles are rendered sample by sample from the second launch on, keep a
+        // third more: config 4's cliff lies between 350 and 300.)
+        if (spp > 1) ra.abort_ticks += ra.abort_ticks / 3;
     }
     ra.few_tiles = c->few_tiles;
     const long long abort_with_cover = ra.abort_ticks;

@@ -2158,7 +2158,10 @@ hipError_t launch_render_split(const SceneDev& sc, const RenderArgs& ra, int n_c
     uint64_t blocks = n_tiles * WG_PER_TILE;               // were every tile split
     // (workgroups per CU at most: 2 / 3 / 4 / 6: config 2 0.63 / 0.51 / 0.49 / 0.51 ms, config 3 0.97 / 0.93 / 0.87 / 0.86,
     // config 4 8.8 throughout)
-    const uint64_t cap = (uint64_t)n_cus * (alone ? (uint64_t)HVRT_SPLIT_WAVES : 4u);
+#ifndef HVRT_SPLIT_WGS
+#define HVRT_SPLIT_WGS 4
+#endif
+    const uint64_t cap = (uint64_t)n_cus * (alone ? (uint64_t)HVRT_SPLIT_WAVES : (uint64_t)(rays == 8 ? HVRT_SPLIT_WGS : 4));
     if (blocks > cap) blocks = cap;
     // (the caller's idea of how many tiles there are, when it has one: twice the workgroups they need, 16 at least --
     // the items are dealt round-robin, so a count that was too low costs time, not tiles)

@@ -377,7 +377,7 @@ def test_split_tiles_change_nothing(ctx, mode):
 
 def test_tiles_given_up_on_are_rendered_by_the_split_kernel(monkeypatch):
     """A launch without tile history runs the k_render variant that gives up on a tile whose rays are still inside
-    long lists after HVRT_TILE_ABORT_US (1 ms by default); k_render_split renders those tiles behind it.  With
+    long lists after HVRT_TILE_ABORT_US (0.3 ms by default); k_render_split renders those tiles behind it.  With
     the limit at 1 us every tile that meets a list of more than 32 entries takes that route: the frames (first
     launch of each shape), hit ids, t and counters are still the oracle's, in both modes, with 1 and 3 samples."""
     import raytracer_amd as ra
