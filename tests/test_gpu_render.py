@@ -638,6 +638,53 @@ def test_render_under_every_scheduling_switch(monkeypatch, env):
         own.close()
 
 
+@pytest.mark.parametrize("inline", ["1", "0"])
+def test_the_walk_that_looks_ahead_on_hard_cameras(monkeypatch, inline):
+    """trace_ray_ahead (k_render_split's walk: the ray's next voxels from its steps alone, their list bounds fetched
+    together, looked at in the ray's order) on every tile that meets an occupied voxel: with HVRT_TILE_ORDER=0 every plain
+    launch is one without history, with HVRT_FEW_TILES at a million it gives all its tiles up at once.  Cameras inside the
+    grid, a million units away, oblique (start voxel clamped on three axes), degenerate directions on the middle row and
+    column, rays that leave the grid in the middle of a batch, grids one voxel wide (the step's increments coincide), odd
+    frame sizes, supersampling; per-reference records and indexed ones.  Frames bit for bit the oracle's."""
+    import raytracer_amd as ra
+    monkeypatch.setenv("HVRT_TILE_ORDER", "0")
+    monkeypatch.setenv("HVRT_FEW_TILES", "1000000")
+    monkeypatch.setenv("HVRT_INLINE_RECORDS", inline)
+    own = ra.Context(0)
+
+    def plain(fr, W, H, **kw):
+        rgb, hit, t, none = own.render(fr, W, H, want_counters=False, **kw)
+        assert none is None
+        return rgb, hit, t, None
+    try:
+        tris = meshgen.cube_sphere(16)
+        sc, mn, mx = setup_scene(own, tris, (24, 24, 24))
+        hits = 0
+        for pos, la in [((0.1, 0.05, 0.2), (1, 0.3, 0.2)), ((0, 0, -1e6), (0, 0, 0)), ((40, 30, -20), (0, 0, 0)),
+                        ((0.5, 0.5, 0.5), (0.5, 0.5, 5)), ((0, 0, -2.5), (0, 0, 0)), ((3, 0, 0), (0, 0, 0))]:
+            fr = capi.make_camera_frame(pos, la, (0, 1, 0), 60.0, 4 / 3)
+            for (W, H) in ((160, 120), (63, 65), (9, 7)):
+                got = plain(fr, W, H)
+                assert_frames_equal(got, sc.render(fr, W, H, threads=8)[:3] + (None,))
+                hits += int((got[1] != MISS).sum())
+        assert hits > 10000
+        fr = capi.make_camera_frame(*capi.default_camera(mn, mx, aspect=16 / 9))
+        assert_frames_equal(plain(fr, 192, 108, spp=4, seed=7), sc.render(fr, 192, 108, spp=4, seed=7, threads=8)[:3] + (None,))
+        for dims in ((1, 24, 24), (24, 1, 24), (24, 24, 1), (1, 1, 24), (40, 13, 27)):
+            sc, mn, mx = setup_scene(own, tris, dims)
+            for view in ("front", "side", "top"):
+                fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view))
+                assert_frames_equal(plain(fr, 200, 150), sc.render(fr, 200, 150, threads=8)[:3] + (None,))
+        for name in ("slivers", "random_soup", "skewed_long_lists", "offcentre_noncubic"):
+            gen, dims, (W, H) = SCENES[name]
+            sc, mn, mx = setup_scene(own, gen(), dims)
+            for view in ("front", "side", "top"):
+                fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view))
+                assert_frames_equal(plain(fr, W, H), sc.render(fr, W, H, threads=8)[:3] + (None,))
+    finally:
+        own.close()
+
+
 @pytest.mark.parametrize("name", ["sphere_16", "slivers", "skewed_long_lists"])
 def test_render_from_an_ingested_cpu_grid(ctx, name):
     """IRayTracer's constructor path: the CSR comes from the CPU (hvrt_set_grid_csr); the skip bits are
