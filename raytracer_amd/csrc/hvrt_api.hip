@@ -110,6 +110,8 @@ struct hvrt_ctx {
     // config 3 1.86 / 1.81 / 1.70 / 1.99 / 2.58 / 3.78, config 4 16.3 / 14.6 / 13.9 / 15.7 / 15.9 / 18.2)
     long long abort_ticks = 30000;       // HVRT_TILE_ABORT_US: 300 us (see render_batch_part)
     uint32_t few_tiles = 2048;           // HVRT_FEW_TILES (RenderArgs::few_tiles)
+    uint32_t few_serial = 0;             // number of the last launch that ran the give-up variant with a report (split_hint[2], [3]); 0: the last launch did not
+    uint32_t few_counter = 0;
     hipEvent_t ev_split_fork = nullptr, ev_split_join = nullptr;
     hipEvent_t ev_fill_fork = nullptr, ev_fill_join = nullptr;      // k_fill_background runs beside the traversal, on df_stream
     // pinned, written by k_order_scan: how many tiles the last order build found that qualify for k_render_split.
@@ -492,7 +494,7 @@ int hvrt_create(hvrt_ctx** out, int device_id) {
     if ((e = hipEventCreateWithFlags(&c->ev_fill_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&c->ev_split_join, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipHostMalloc((void**)&c->split_hint, 128, hipHostMallocDefault)) != hipSuccess) return bail("hipHostMalloc", e);
-    c->split_hint[0] = 1u; c->split_hint[1] = 0u;
+    c->split_hint[0] = 1u; c->split_hint[1] = 0u; c->split_hint[2] = 0u; c->split_hint[3] = 0u;
     c->stats_host = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(c->split_hint) + 64);      // 8 words of the same pinned block
     if ((e = hipHostGetDevicePointer((void**)&c->split_hint_dev, c->split_hint, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
     for (auto& ev : c->ev)
@@ -1175,7 +1177,14 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
     // unordered one (config 2, an orbit in steps of 2 / 3 / 5 / 7 degrees: 1.55 / 1.71 / 1.89 / 2.09 ms per frame with the
     // previous frame's durations, 1.69-1.75 with none; scripts/time_moving.py), so past 2.5 degrees this is a first launch
     const bool view_moved = c->history_max_rad > 0.0f && c->cost_valid && view_distance(c, frames[0], c->cost_cam) > c->history_max_rad;
-    const bool reuse = c->adaptive_order && c->cost_valid && c->order_ahead && !grew && !view_moved && memcmp(key, c->cost_key, sizeof key) == 0;
+    // A launch that gave all its tiles up at once because they were few (RenderArgs::few_tiles) leaves durations that are sums
+    // over the split kernel's pieces: they rank the tiles poorly (config 2 at 800x600: 0.74 ms for the launch ordered by them,
+    // 0.42 for one that gives everything up again).  If that launch has run by now and said so, this one is another of its kind.
+    bool last_was_few = false;
+    if (c->few_serial != 0u && __atomic_load_n(c->split_hint + 3, __ATOMIC_ACQUIRE) == c->few_serial)
+        last_was_few = __atomic_load_n(c->split_hint + 2, __ATOMIC_RELAXED) != 0u;
+    c->few_serial = 0u;
+    const bool reuse = c->adaptive_order && c->cost_valid && c->order_ahead && !grew && !view_moved && !last_was_few && memcmp(key, c->cost_key, sizeof key) == 0;
     c->order_ahead = false;
 
     RenderArgs ra;
@@ -1213,7 +1222,9 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         // third more: config 4's cliff lies between 350 and 300.)
         if (spp > 1) ra.abort_ticks += ra.abort_ticks / 3;
     }
-    ra.few_tiles = c->few_tiles;
+    // (the split kernel cuts a tile into sixteen pieces where the grid's lists are long, into eight otherwise: half the tiles
+    // make as many pieces -- config 3 at 1080p, some 1 500 marked tiles: 0.9 ms given up at once, 0.75 with history)
+    ra.few_tiles = c->max_list > 256u ? c->few_tiles / 2u : c->few_tiles; ra.few_report = nullptr; ra.few_serial = 0u;
     const long long abort_with_cover = ra.abort_ticks;
     ra.abort_ticks *= 2;      // (every tile walked, the GPU full from end to end: twice the time; halved below where a tile cover is in use)
     ra.tile_cost = c->tile_cost;
@@ -1357,6 +1368,11 @@ static int render_batch_part(hvrt_ctx* c, const hvrt_camera_frame* frames, int n
         // as a rule: it then finds an empty list and ends)
         const bool abortable = c->adaptive_split && n_tiles != 0 && c->abort_ticks > 0;    // HVRT_TILE_ABORT_US=0: never give up
         if (int r = start_fill()) return r;
+        if (abortable && ra.n_queue && ra.few_tiles) {
+            if (++c->few_counter == 0u) c->few_counter = 1u;
+            c->few_serial = c->few_counter;
+            ra.few_report = c->split_hint_dev + 2; ra.few_serial = c->few_serial;
+        }
         HIP_TRY(c, launch_render(scene_of(c), ra, c->n_cus, abortable, s));
         if (abortable) {
             RenderArgs rb = ra;
@@ -1533,7 +1549,7 @@ int hvrt_render_part_device_noalloc(hvrt_ctx* c, const hvrt_camera_frame* frame,
     ra.n_heads = 1;
     ra.order = nullptr;                 // no history is kept between these calls: rows of tiles from the middle outwards
     ra.split_tiles = nullptr; ra.n_split = nullptr;
-    ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_ticks = 0; ra.few_tiles = 0;   // the plain kernel: no tile is handed on
+    ra.abandoned = nullptr; ra.n_abandoned = nullptr; ra.abort_ticks = 0; ra.few_tiles = 0; ra.few_report = nullptr; ra.few_serial = 0;   // the plain kernel: no tile is handed on
     ra.tile_cost = (uint32_t*)(sp + NOALLOC_TILE_COST);
     ra.cost_sum = (unsigned long long*)(sp + NOALLOC_COST_SUM);
     // the array keeps the last call's contents: the queue head and the duration sum must start at zero (the

@@ -104,6 +104,10 @@ struct RenderArgs {
     // first occupied voxel its rays reach: the GPU is all but empty, and k_render_split behind it walks each tile with
     // sixteen waves that look ahead (trace_ray_ahead) instead of one that cannot.  0: never.
     uint32_t few_tiles;
+    // (nullable) two words of pinned host memory: the give-up variant leaves there whether it took that course, then
+    // few_serial -- a host that finds the serial of its last launch knows that the launch left no durations worth an order
+    uint32_t* few_report;
+    uint32_t few_serial;
     uint32_t* tile_cost;
     unsigned long long* cost_sum;   // sum of tile_cost over this launch (zeroed before it)
     unsigned long long* walked;     // (nullable) += the tiles this launch walked (zeroed before it; the order build reads it at cost_sum[2])

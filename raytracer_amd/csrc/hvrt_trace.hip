@@ -1396,6 +1396,11 @@ __device__ __forceinline__ void render_tiles(const SceneDev& sc, const RenderArg
     if (blockIdx.x == 0 && threadIdx.x == 0) ra.abandoned[0] = (uint32_t)life_wall0;
 #endif
 #endif
+    if (ABORT && ra.few_report && blockIdx.x == 0 && threadIdx.x == 0) {
+        // (the verdict, then the launch's number: see RenderArgs::few_report)
+        __hip_atomic_store(ra.few_report, ra.n_queue && n_queue <= ra.few_tiles ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(ra.few_report + 1, ra.few_serial, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     uint32_t tot_hits = 0;                // wave-uniform
 #if defined(HVRT_DIAG) && HVRT_DIAG == 41
     uint32_t n_done = 0;
