@@ -681,6 +681,13 @@ def test_the_walk_that_looks_ahead_on_hard_cameras(monkeypatch, inline):
             for view in ("front", "side", "top"):
                 fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view))
                 assert_frames_equal(plain(fr, W, H), sc.render(fr, W, H, threads=8)[:3] + (None,))
+        # the nearest-hit mode takes the same route (its split kernel keeps the walk that does not look ahead)
+        sc, mn, mx = setup_scene(own, tris, (24, 24, 24))
+        own.set_mode(1)
+        sc.set_mode(1, mx)
+        for view in ("front", "side", "top"):
+            fr = capi.make_camera_frame(*capi.default_camera(mn, mx, view))
+            assert_frames_equal(plain(fr, 200, 150), sc.render(fr, 200, 150, threads=8)[:3] + (None,))
     finally:
         own.close()
 
