@@ -18,6 +18,15 @@ ctx.set_mesh(tris)
 mn, mx = ctx.mesh_bounds()
 vs = capi.voxel_size(mn, mx, g, g, g)
 ctx.build_grid(g, g, g, mn, mx, vs)
+# a second context on the same scene whose launches never have history: the give-up variant (all tiles at once where they
+# are few) and the split kernel's walk that looks ahead behind it
+os.environ["HVRT_TILE_ORDER"] = "0"
+ctx2 = ra.Context(0)
+del os.environ["HVRT_TILE_ORDER"]
+info = ctx.grid_info()
+a_, o_, i_ = ctx.device_arrays()
+ctx2.set_mesh_device(a_, info.n_triangles)
+ctx2.set_grid_csr_device(g, g, g, mn, mx, np.asarray([vs] * 3, np.float32), o_, i_, info.n_refs)
 c = 0.5 * (np.asarray(mn, np.float64) + np.asarray(mx, np.float64))
 ext = float(np.max(np.asarray(mx) - np.asarray(mn)))
 bad = 0
@@ -39,7 +48,11 @@ for k in range(n):
             ctx.render_part_device(fr, W, H, 1, 0, H, 0, 1, rgb.data_ptr(), hit.data_ptr(), t.data_ptr(), cnt.data_ptr() if counters else 0)
             ctx.synchronize()
         bufs.append((rgb, hit, t))
-    same = bool((bufs[0][1] == bufs[1][1]).all()) and bool((bufs[0][2].view(torch.int32) == bufs[1][2].view(torch.int32)).all()) \
+    rgb2 = torch.empty((H, W, 3), dtype=torch.float32, device="cuda:0"); hit2 = torch.empty((H, W), dtype=torch.int32, device="cuda:0"); t2 = torch.empty((H, W), dtype=torch.float32, device="cuda:0")
+    ctx2.render_part_device(fr, W, H, 1, 0, H, 0, 1, rgb2.data_ptr(), hit2.data_ptr(), t2.data_ptr(), 0)
+    ctx2.synchronize()
+    same2 = bool((bufs[0][1] == hit2).all()) and bool((bufs[0][2].view(torch.int32) == t2.view(torch.int32)).all()) and bool((bufs[0][0].view(torch.int32) == rgb2.view(torch.int32)).all())
+    same = same2 and bool((bufs[0][1] == bufs[1][1]).all()) and bool((bufs[0][2].view(torch.int32) == bufs[1][2].view(torch.int32)).all()) \
         and bool((bufs[0][0].view(torch.int32) == bufs[1][0].view(torch.int32)).all())
     cov = ctx.tile_cover()
     hits = float((bufs[0][1] != -1).float().mean())
